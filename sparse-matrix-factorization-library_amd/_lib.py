@@ -1,0 +1,69 @@
+"""ctypes loader for libsparseframe_hip.so.  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparseframe_hip.so")
+
+
+class SparseFrameError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C sparse-matrix-factorization-library_amd/csrc`). There is no Python/CPU fallback.")
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+c_long_p = C.POINTER(C.c_int64)
+c_double_p = C.POINTER(C.c_double)
+
+# ---- flat ABI signatures (include/sparseframe_hip.h, layer 2) ----
+lib.sf_version.restype = C.c_char_p
+lib.sf_device_count.restype = C.c_int
+
+lib.sf_symbolic_create.argtypes = [C.POINTER(C.c_void_p), C.c_int64, c_long_p, c_long_p, c_double_p, c_long_p, C.c_size_t]
+lib.sf_symbolic_create.restype = C.c_int
+lib.sf_symbolic_destroy.argtypes = [C.c_void_p]
+lib.sf_symbolic_destroy.restype = None
+lib.sf_symbolic_scalar.argtypes = [C.c_void_p, C.c_char_p]
+lib.sf_symbolic_scalar.restype = C.c_int64
+lib.sf_symbolic_long_array.argtypes = [C.c_void_p, C.c_char_p, c_long_p]
+lib.sf_symbolic_long_array.restype = c_long_p
+lib.sf_symbolic_float_array.argtypes = [C.c_void_p, C.c_char_p, c_long_p]
+lib.sf_symbolic_float_array.restype = c_double_p
+lib.sf_symbolic_flops.argtypes = [C.c_void_p, C.c_int]
+lib.sf_symbolic_flops.restype = C.c_double
+lib.sf_grid_nd_perm.argtypes = [C.c_int64] * 5 + [c_long_p]
+lib.sf_grid_nd_perm.restype = C.c_int
+
+lib.sf_chol_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7
+lib.sf_chol_plan_create.restype = C.c_int
+lib.sf_chol_plan_set_values.argtypes = [C.c_void_p, c_double_p]
+lib.sf_chol_plan_set_values.restype = C.c_int
+lib.sf_chol_plan_factorize.argtypes = [C.c_void_p, C.c_int]
+lib.sf_chol_plan_factorize.restype = C.c_int
+lib.sf_chol_plan_sync.argtypes = [C.c_void_p]
+lib.sf_chol_plan_sync.restype = C.c_int
+lib.sf_chol_plan_get_factor.argtypes = [C.c_void_p, c_double_p]
+lib.sf_chol_plan_get_factor.restype = C.c_int
+lib.sf_chol_plan_factor_device_ptr.argtypes = [C.c_void_p]
+lib.sf_chol_plan_factor_device_ptr.restype = C.c_void_p
+lib.sf_chol_plan_solve.argtypes = [C.c_void_p, c_double_p, c_double_p]
+lib.sf_chol_plan_solve.restype = C.c_int
+lib.sf_chol_plan_stat.argtypes = [C.c_void_p, C.c_char_p]
+lib.sf_chol_plan_stat.restype = C.c_double
+lib.sf_chol_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
+lib.sf_chol_plan_set_profiling.restype = C.c_int
+lib.sf_chol_plan_destroy.argtypes = [C.c_void_p]
+lib.sf_chol_plan_destroy.restype = C.c_int
+
+ERR_NAMES = {0: "SF_OK", 1: "SF_ERR_ARG", 2: "SF_ERR_NO_DEVICE", 3: "SF_ERR_ALLOC",
+             4: "SF_ERR_NOT_POSDEF", 5: "SF_ERR_HIP"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SparseFrameError(f"{what} failed: {ERR_NAMES.get(rc, rc)}")

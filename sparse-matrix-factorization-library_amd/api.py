@@ -1,0 +1,293 @@
+"""Python mirror of the reference's operator interface for the numeric-factorization path.
+
+Two views of the same C ABI (include/sparseframe_hip.h):
+
+* ``MatrixInfo`` / ``CommonInfo`` wrap ``struct matrix_info_struct`` / ``struct common_info_struct``
+  (reference Cholesky/Include/info.h:12-29, :70-150) and call the struct-based entry points with the
+  reference's own names: ``analyze`` -> SparseFrame_analyze (SparseFrame.c:1916), ``factorize`` ->
+  SparseFrame_factorize (:3019), ``solve`` -> SparseFrame_solve_supernodal (:3036), ``validate`` ->
+  SparseFrame_validate (:3141), ``cleanup`` -> SparseFrame_cleanup_matrix (:3268).
+* ``Symbolic`` / ``CholPlan`` wrap the flat plan ABI (sf_symbolic_*, sf_chol_plan_*), which keeps the
+  factor resident in HBM between calls -- this is what bench.py times.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, check, c_long_p, c_double_p, SparseFrameError
+
+# devSlotSize the reference computes (SparseFrame.c:82-87,199) for 288 GiB devices
+REFERENCE_SLOT_1GPU = 8_694_792_192     # 1 device  -> numSplit 4
+REFERENCE_SLOT_8GPU = 34_781_265_920    # >=4 devices -> numSplit 1
+
+
+def _lp(a):
+    return a.ctypes.data_as(c_long_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    return int(lib.sf_device_count())
+
+
+def grid_nd_perm(nx, ny=1, nz=1, leaf=3, sep_width=1):
+    """Deterministic geometric nested dissection of a regular grid; perm[new] = old."""
+    perm = np.empty(nx * ny * nz, dtype=np.int64)
+    check(lib.sf_grid_nd_perm(nx, ny, nz, leaf, sep_width, _lp(perm)), "sf_grid_nd_perm")
+    return perm
+
+
+class Symbolic:
+    """Result of the host-side symbolic analysis (flat ABI)."""
+
+    LONG_ARRAYS = ("Perm", "Parent", "Parent0", "Post", "ColCount", "ColCount0", "Lp", "Li", "LTp", "LTi",
+                   "Super", "SuperMap", "Sparent", "Lsip", "Lsxp", "Lsi", "LeafQueue",
+                   "ST_Map", "ST_Pointer", "ST_Index", "Aoffset", "Moffset")
+    SCALARS = ("n", "nnz", "nfsuper", "nsuper", "nstage", "isize", "xsize", "csize", "nsleaf")
+
+    def __init__(self, n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU):
+        Cp, Ci, Cx = _i64(Cp), _i64(Ci), _f64(Cx)
+        if perm is not None:
+            perm = _i64(perm)
+        h = C.c_void_p()
+        check(lib.sf_symbolic_create(C.byref(h), n, _lp(Cp), _lp(Ci), _dp(Cx),
+                                     _lp(perm) if perm is not None else None, dev_slot_size),
+              "sf_symbolic_create")
+        self._h = h
+        self._cache = {}
+        self.dev_slot_size = dev_slot_size
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sf_symbolic_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        if name in Symbolic.SCALARS:
+            return int(lib.sf_symbolic_scalar(self._h, name.encode()))
+        if name in Symbolic.LONG_ARRAYS:
+            if name not in self._cache:
+                ln = C.c_int64()
+                p = lib.sf_symbolic_long_array(self._h, name.encode(), C.byref(ln))
+                self._cache[name] = (np.ctypeslib.as_array(p, shape=(ln.value,)).copy()
+                                     if ln.value else np.zeros(0, np.int64))
+            return self._cache[name]
+        if name in ("Lx", "LTx"):
+            if name not in self._cache:
+                ln = C.c_int64()
+                p = lib.sf_symbolic_float_array(self._h, name.encode(), C.byref(ln))
+                self._cache[name] = (np.ctypeslib.as_array(p, shape=(ln.value,)).copy()
+                                     if ln.value else np.zeros(0))
+            return self._cache[name]
+        raise AttributeError(name)
+
+    @property
+    def flops_struct(self):
+        return float(lib.sf_symbolic_flops(self._h, 0))
+
+    @property
+    def flops_exec(self):
+        return float(lib.sf_symbolic_flops(self._h, 1))
+
+    @property
+    def flops_update(self):
+        return float(lib.sf_symbolic_flops(self._h, 2))
+
+    @property
+    def scatter_elems(self):
+        return float(lib.sf_symbolic_flops(self._h, 3))
+
+
+def analyze(n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU):
+    return Symbolic(n, Cp, Ci, Cx, perm, dev_slot_size)
+
+
+class CholPlan:
+    """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present."""
+
+    def __init__(self, sym, device=0):
+        h = C.c_void_p()
+        self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
+        check(lib.sf_chol_plan_create(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep]),
+              "sf_chol_plan_create")
+        self._h = h
+        self.xsize = sym.xsize
+        self.n = sym.n
+
+    def set_values(self, Lx):
+        Lx = _f64(Lx)
+        check(lib.sf_chol_plan_set_values(self._h, _dp(Lx)), "sf_chol_plan_set_values")
+
+    def factorize(self, sync=True):
+        check(lib.sf_chol_plan_factorize(self._h, 1 if sync else 0), "sf_chol_plan_factorize")
+
+    def sync(self):
+        check(lib.sf_chol_plan_sync(self._h), "sf_chol_plan_sync")
+
+    def get_factor(self):
+        out = np.empty(max(self.xsize, 1), dtype=np.float64)
+        check(lib.sf_chol_plan_get_factor(self._h, _dp(out)), "sf_chol_plan_get_factor")
+        return out[:self.xsize]
+
+    def solve(self, b):
+        b = _f64(b)
+        x = np.empty_like(b)
+        check(lib.sf_chol_plan_solve(self._h, _dp(b), _dp(x)), "sf_chol_plan_solve")
+        return x
+
+    def stat(self, name):
+        return float(lib.sf_chol_plan_stat(self._h, name.encode()))
+
+    def set_profiling(self, on=True):
+        check(lib.sf_chol_plan_set_profiling(self._h, 1 if on else 0), "sf_chol_plan_set_profiling")
+
+    @property
+    def factor_device_ptr(self):
+        return lib.sf_chol_plan_factor_device_ptr(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sf_chol_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+# -------------------------------------------------------------------------------------------------
+# struct-based interface (reference names)
+# -------------------------------------------------------------------------------------------------
+class CommonInfoStruct(C.Structure):       # info.h:12-29
+    _fields_ = [("numCPU", C.c_int), ("numGPU", C.c_int), ("numGPU_physical", C.c_int),
+                ("minDevMemSize", C.c_size_t), ("minHostMemSize", C.c_size_t),
+                ("matrixThreadNum", C.c_int), ("numSparseMatrix", C.c_int),
+                ("devSlotSize", C.c_size_t),
+                ("allocateTime", C.c_double), ("computeTime", C.c_double), ("freeTime", C.c_double)]
+
+
+class MatrixInfoStruct(C.Structure):       # info.h:70-150
+    _fields_ = [("serial", C.c_int), ("path", C.c_char_p), ("file", C.c_void_p),
+                ("factorizeType", C.c_int), ("isSymmetric", C.c_int), ("isComplex", C.c_int),
+                ("ncol", C.c_int64), ("nrow", C.c_int64), ("nzmax", C.c_int64),
+                ("Tj", c_long_p), ("Ti", c_long_p), ("Tx", c_double_p),
+                ("Cp", c_long_p), ("Ci", c_long_p), ("Cx", c_double_p),
+                ("Lp", c_long_p), ("Li", c_long_p), ("Lx", c_double_p),
+                ("LTp", c_long_p), ("LTi", c_long_p), ("LTx", c_double_p),
+                ("permMethod", C.c_int),
+                ("Perm", c_long_p), ("Parent", c_long_p), ("Post", c_long_p), ("ColCount", c_long_p),
+                ("nsuper", C.c_int64), ("Super", c_long_p), ("SuperMap", c_long_p), ("Sparent", c_long_p),
+                ("nsleaf", C.c_int64), ("LeafQueue", c_long_p),
+                ("isize", C.c_int64), ("xsize", C.c_int64),
+                ("Lsip", c_long_p), ("Lsxp", c_long_p), ("Lsi", c_long_p), ("Lsx", c_double_p),
+                ("csize", C.c_int64), ("nstage", C.c_int64),
+                ("ST_Map", c_long_p), ("ST_Pointer", c_long_p), ("ST_Index", c_long_p), ("ST_Parent", c_long_p),
+                ("Aoffset", C.POINTER(C.c_size_t)), ("Moffset", C.POINTER(C.c_size_t)),
+                ("workspace", C.c_void_p), ("workSize", C.c_size_t),
+                ("Bx", c_double_p), ("Xx", c_double_p), ("Rx", c_double_p),
+                ("residual", C.c_double),
+                ("readTime", C.c_double), ("analyzeTime", C.c_double),
+                ("factorizeTime", C.c_double), ("solveTime", C.c_double)]
+
+
+for _name, _args in (("SparseFrame_allocate_gpu", [C.POINTER(CommonInfoStruct), C.POINTER(C.c_void_p)]),
+                     ("SparseFrame_free_gpu", [C.POINTER(CommonInfoStruct), C.POINTER(C.c_void_p)]),
+                     ("SparseFrame_initialize_matrix", [C.POINTER(MatrixInfoStruct)]),
+                     ("SparseFrame_read_matrix", [C.POINTER(MatrixInfoStruct)]),
+                     ("SparseFrame_set_matrix_csc", [C.POINTER(MatrixInfoStruct), C.c_int64, C.c_int64,
+                                                     c_long_p, c_long_p, c_double_p, C.c_int]),
+                     ("SparseFrame_set_perm", [C.POINTER(MatrixInfoStruct), c_long_p]),
+                     ("SparseFrame_analyze", [C.POINTER(CommonInfoStruct), C.POINTER(MatrixInfoStruct)]),
+                     ("SparseFrame_factorize", [C.POINTER(CommonInfoStruct), C.c_void_p, C.POINTER(MatrixInfoStruct)]),
+                     ("SparseFrame_factorize_supernodal", [C.POINTER(CommonInfoStruct), C.c_void_p, C.POINTER(MatrixInfoStruct)]),
+                     ("SparseFrame_solve_supernodal", [C.POINTER(MatrixInfoStruct)]),
+                     ("SparseFrame_validate", [C.POINTER(MatrixInfoStruct)]),
+                     ("SparseFrame_cleanup_matrix", [C.POINTER(MatrixInfoStruct)])):
+    _f = getattr(lib, _name)
+    _f.argtypes = _args
+    _f.restype = C.c_int
+
+
+class CommonInfo:
+    """common_info_struct + the opaque gpu_info list (SparseFrame_allocate_gpu / _free_gpu)."""
+
+    def __init__(self, dev_slot_size=None):
+        self.c = CommonInfoStruct()
+        self.gpu_list = C.c_void_p()
+        check(lib.SparseFrame_allocate_gpu(C.byref(self.c), C.byref(self.gpu_list)), "SparseFrame_allocate_gpu")
+        if dev_slot_size is not None:
+            self.c.devSlotSize = dev_slot_size
+
+    def close(self):
+        if self.gpu_list:
+            lib.SparseFrame_free_gpu(C.byref(self.c), C.byref(self.gpu_list))
+            self.gpu_list = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MatrixInfo:
+    """matrix_info_struct driven through the reference's stage functions."""
+
+    def __init__(self, serial=0):
+        self.c = MatrixInfoStruct()
+        self.c.serial = serial
+        lib.SparseFrame_initialize_matrix(C.byref(self.c))
+
+    def set_csc(self, n, Cp, Ci, Cx, symmetric=True):
+        Cp, Ci, Cx = _i64(Cp), _i64(Ci), _f64(Cx)
+        check(lib.SparseFrame_set_matrix_csc(C.byref(self.c), n, len(Ci), _lp(Cp), _lp(Ci), _dp(Cx),
+                                             1 if symmetric else 0), "SparseFrame_set_matrix_csc")
+
+    def read(self, path):
+        self._path = str(path).encode()
+        self.c.path = self._path
+        check(lib.SparseFrame_read_matrix(C.byref(self.c)), "SparseFrame_read_matrix")
+
+    def set_perm(self, perm):
+        perm = _i64(perm)
+        check(lib.SparseFrame_set_perm(C.byref(self.c), _lp(perm)), "SparseFrame_set_perm")
+
+    def analyze(self, common):
+        check(lib.SparseFrame_analyze(C.byref(common.c), C.byref(self.c)), "SparseFrame_analyze")
+
+    def factorize(self, common):
+        check(lib.SparseFrame_factorize(C.byref(common.c), common.gpu_list, C.byref(self.c)), "SparseFrame_factorize")
+
+    def validate(self):
+        check(lib.SparseFrame_validate(C.byref(self.c)), "SparseFrame_validate")
+        return float(self.c.residual)
+
+    def cleanup(self):
+        lib.SparseFrame_cleanup_matrix(C.byref(self.c))
+
+    def array(self, name, length):
+        p = getattr(self.c, name)
+        if not p or length == 0:
+            return np.zeros(0, dtype=np.float64 if name.endswith("x") else np.int64)
+        return np.ctypeslib.as_array(p, shape=(length,))
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass

@@ -1,0 +1,486 @@
+// Device plan of the supernodal Cholesky numeric factorization.
+//
+// Replaces the reference's task-queue scheduler and GPU branch (Cholesky/Source/SparseFrame.c:2150-3017).
+// The reference is left-looking with descendant lists, one supernode at a time, every panel staged over
+// PCIe (C:2345-2954).  Here the whole factor stays resident in HBM and the elimination tree is swept
+// level by level (level = height above the leaves in the supernodal tree, parent as in C:2247):
+//
+//   memset(Lsx) ; k_load_panels                                          (loadA, C:1998-2028)
+//   for level l = 0 .. L-1:
+//       for t = 0 .. ceil(max nscol / 64)-1:          in-panel right-looking blocked factorization
+//           k_potrf_block  on every panel of the level with nscol > 64 t
+//           k_trsm_block   on the rows below that block
+//           k_gemm<0>      trailing update of the remaining panel columns  (K = 64)
+//       k_gemm<1>          every (supernode of the level -> ancestor) Schur update, scatter fused
+//
+// A supernode's updates are pushed to all its ancestors as soon as it is factored (right-looking);
+// the sums are the same as the reference's left-looking sums, applied in a different order, so the
+// factor agrees to rounding (the reference itself is order-nondeterministic: qsort + atomicAdd).
+// All task tables depend on the structure only and are built once at plan creation.
+#include <sparseframe_hip.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sf_kernels.h"
+
+using sf::GemmProb;
+using sf::GemmTask;
+using sf::PotrfTask;
+using sf::TrsmTask;
+
+namespace {
+
+struct Launch {
+    int kind;       // 0 potrf, 1 trsm, 2 gemm panel, 3 gemm scatter
+    int64_t first;  // first task
+    int count;
+};
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            fprintf(stderr, "[sparseframe-hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SF_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+template <class T>
+int upload(T** dptr, const std::vector<T>& h, size_t* bytes_total) {
+    *dptr = nullptr;
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dptr, bytes));
+    if (!h.empty()) HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes_total += bytes;
+    return SF_OK;
+}
+
+}  // namespace
+
+struct sf_chol_plan {
+    int device = 0;
+    int64_t n = 0, nsuper = 0, nnz = 0, isize = 0, xsize = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // device copies of the structure
+    int64_t* d_Lp = nullptr;
+    int32_t* d_Li = nullptr;
+    double* d_Lx = nullptr;
+    int32_t* d_Super = nullptr;
+    int32_t* d_SuperMap = nullptr;
+    int64_t* d_Lsip = nullptr;
+    int32_t* d_Lsi = nullptr;
+    int64_t* d_Lsxp = nullptr;
+    double* d_Lsx = nullptr;
+    int* d_info = nullptr;
+
+    PotrfTask* d_potrf = nullptr;
+    TrsmTask* d_trsm = nullptr;
+    GemmProb* d_probs = nullptr;
+    GemmTask* d_gtasks = nullptr;
+
+    std::vector<Launch> launches;
+    int nlevels = 0;
+    int64_t n_gemm_tasks = 0, n_pairs = 0;
+    double flops_exec = 0, flops_update = 0, scatter_elems = 0, flops_panel_gemm = 0;
+    size_t bytes_device = 0;
+    bool values_set = false;
+
+    bool profiling = false;
+    double last_ms = 0, last_load_ms = 0, last_panel_ms = 0, last_update_ms = 0;
+    int last_status = SF_OK;
+
+    // host copies needed by the device solve
+    std::vector<int64_t> h_Lsip, h_Lsxp;
+    std::vector<int32_t> h_Super;
+    std::vector<int> level_of;
+};
+
+extern "C" {
+
+int sf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sf_chol_plan_destroy(sf_chol_plan* p) {
+    if (!p) return SF_OK;
+    (void)hipSetDevice(p->device);
+    void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
+                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return SF_OK;
+}
+
+int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
+                        const sf_long* Super, const sf_long* SuperMap,
+                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                        const sf_long* Lp, const sf_long* Li) {
+    if (!out) return SF_ERR_ARG;
+    *out = nullptr;
+    if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
+    if (n >= (sf_long)0x7fffffff) return SF_ERR_ARG;   // device row indices are 32-bit
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[sparseframe-hip] no HIP device: the numeric factorization has no CPU fallback\n");
+        return SF_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+
+    sf_chol_plan* p = new (std::nothrow) sf_chol_plan();
+    if (!p) return SF_ERR_ALLOC;
+    p->device = device;
+    p->n = n;
+    p->nsuper = nsuper;
+    p->nnz = Lp[n];
+    p->isize = Lsip[nsuper];
+    p->xsize = Lsxp[nsuper];
+
+    // ---------------- validate the structure the kernels index with ----------------
+    for (sf_long s = 0; s < nsuper; ++s) {
+        const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        if (nscol <= 0 || nsrow < nscol || Lsxp[s + 1] - Lsxp[s] != nscol * nsrow || nsrow >= (sf_long)0x7fffffff) {
+            delete p;
+            return SF_ERR_ARG;
+        }
+        for (sf_long k = 0; k < nsrow; ++k) {
+            const sf_long g = Lsi[Lsip[s] + k];
+            const bool ok = (k < nscol) ? (g == Super[s] + k) : (g > Lsi[Lsip[s] + k - 1] && g < n);
+            if (!ok) { delete p; return SF_ERR_ARG; }
+        }
+    }
+    if (Super[0] != 0 || Super[nsuper] != n) { delete p; return SF_ERR_ARG; }
+
+    // ---------------- levels of the supernodal tree ----------------
+    std::vector<int> level(nsuper, 0);
+    int nlevels = nsuper > 0 ? 1 : 0;
+    for (sf_long s = 0; s < nsuper; ++s) {
+        const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        if (nscol < nsrow) {
+            const sf_long par = SuperMap[Lsi[Lsip[s] + nscol]];
+            if (par <= s) { delete p; return SF_ERR_ARG; }   // must be postordered
+            level[par] = std::max(level[par], level[s] + 1);
+            nlevels = std::max(nlevels, level[par] + 1);
+        }
+    }
+    p->nlevels = nlevels;
+    p->level_of = level;
+    std::vector<std::vector<sf_long>> by_level(nlevels);
+    for (sf_long s = 0; s < nsuper; ++s) by_level[level[s]].push_back(s);
+
+    // ---------------- task tables ----------------
+    std::vector<PotrfTask> potrf;
+    std::vector<TrsmTask> trsm;
+    std::vector<GemmProb> probs;
+    std::vector<GemmTask> gtasks;
+    auto add_tiles = [&](int32_t prob_id, int M, int N) {
+        const int tmn = (M + sf::GEMM_BM - 1) / sf::GEMM_BM, tnn = (N + sf::GEMM_BN - 1) / sf::GEMM_BN;
+        for (int tn = 0; tn < tnn; ++tn)
+            for (int tm = 0; tm < tmn; ++tm) {
+                // keep tiles that contain at least one element with ci >= cj
+                if ((tm + 1) * sf::GEMM_BM - 1 < tn * sf::GEMM_BN) continue;
+                gtasks.push_back(GemmTask{prob_id, (uint16_t)tm, (uint16_t)tn});
+            }
+    };
+
+    for (int l = 0; l < nlevels; ++l) {
+        const std::vector<sf_long>& Sl = by_level[l];
+        sf_long maxcol = 0;
+        for (sf_long s : Sl) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
+        const int nsteps = (int)((maxcol + sf::NB - 1) / sf::NB);
+        for (int t = 0; t < nsteps; ++t) {
+            const int64_t p0 = (int64_t)potrf.size(), t0 = (int64_t)trsm.size(), g0 = (int64_t)gtasks.size();
+            for (sf_long s : Sl) {
+                const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                const int diag = t * sf::NB;
+                if (diag >= nscol) continue;
+                const int b = std::min(sf::NB, nscol - diag);
+                potrf.push_back(PotrfTask{Lsxp[s], nsrow, diag, b, 0});
+                const int below = diag + b;
+                for (int r = below; r < nsrow; r += sf::TRSM_ROWS)
+                    trsm.push_back(TrsmTask{Lsxp[s], nsrow, diag, b, r, std::min(sf::TRSM_ROWS, nsrow - r), 0});
+                if (below < nscol) {
+                    GemmProb g{};
+                    g.y_off = Lsxp[s] + below + (int64_t)diag * nsrow;
+                    g.x_off = g.y_off;
+                    g.c_off = Lsxp[s] + below + (int64_t)below * nsrow;
+                    g.lda = nsrow; g.ldc = nsrow;
+                    g.M = nsrow - below; g.N = nscol - below; g.K = b;
+                    p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
+                    probs.push_back(g);
+                    add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                }
+            }
+            if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
+            if ((int64_t)trsm.size() > t0) p->launches.push_back(Launch{1, t0, (int)(trsm.size() - t0)});
+            if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
+        }
+        // Schur updates of every supernode of this level into its ancestors
+        const int64_t g0 = (int64_t)gtasks.size();
+        for (sf_long s : Sl) {
+            const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+            const sf_long* rows = Lsi + Lsip[s];
+            const double nk = nscol;
+            p->flops_exec += nk * nk * nk / 3.0 + (double)(nsrow - nscol) * nk * nk;
+            int i = nscol;
+            while (i < nsrow) {
+                const sf_long a = SuperMap[rows[i]];
+                int e = i;
+                while (e < nsrow && SuperMap[rows[e]] == a) ++e;
+                const int dn = e - i, dnm = nsrow - i;
+                GemmProb g{};
+                g.y_off = Lsxp[s] + i;
+                g.x_off = g.y_off;
+                g.c_off = Lsxp[a];
+                g.src_rows = Lsip[s] + i;
+                const int a_nscol = (int)(Super[a + 1] - Super[a]), a_nsrow = (int)(Lsip[a + 1] - Lsip[a]);
+                g.tgt_rows = Lsip[a] + a_nscol;
+                g.lda = nsrow; g.ldc = a_nsrow;
+                g.M = dnm; g.N = dn; g.K = nscol;
+                g.tgt_first_col = (int32_t)Super[a];
+                g.tgt_nscol = a_nscol;
+                g.tgt_nbelow = a_nsrow - a_nscol;
+                probs.push_back(g);
+                add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                const double fl = (double)dn * (dn + 1) * nk + 2.0 * (double)(dnm - dn) * dn * nk;
+                p->flops_update += fl;
+                p->flops_exec += fl;
+                p->scatter_elems += (double)dn * (dn + 1) / 2.0 + (double)(dnm - dn) * dn;
+                p->n_pairs++;
+                i = e;
+            }
+        }
+        if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{3, g0, (int)(gtasks.size() - g0)});
+    }
+    p->n_gemm_tasks = (int64_t)gtasks.size();
+
+    // ---------------- upload ----------------
+    std::vector<int32_t> Li32(p->nnz), Super32(nsuper + 1), SuperMap32(n), Lsi32(p->isize);
+    for (sf_long k = 0; k < p->nnz; ++k) Li32[k] = (int32_t)Li[k];
+    for (sf_long k = 0; k <= nsuper; ++k) Super32[k] = (int32_t)Super[k];
+    for (sf_long k = 0; k < n; ++k) SuperMap32[k] = (int32_t)SuperMap[k];
+    for (sf_long k = 0; k < p->isize; ++k) Lsi32[k] = (int32_t)Lsi[k];
+    std::vector<int64_t> Lp64(Lp, Lp + n + 1), Lsip64(Lsip, Lsip + nsuper + 1), Lsxp64(Lsxp, Lsxp + nsuper + 1);
+    p->h_Lsip = Lsip64; p->h_Lsxp = Lsxp64; p->h_Super = Super32;
+
+    int rc = SF_OK;
+    do {
+        if (hipStreamCreate(&p->stream) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess ||
+            hipEventCreate(&p->ev1) != hipSuccess) { rc = SF_ERR_HIP; break; }
+        if ((rc = upload(&p->d_Lp, Lp64, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_Li, Li32, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_Super, Super32, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_SuperMap, SuperMap32, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_Lsip, Lsip64, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_Lsi, Lsi32, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_Lsxp, Lsxp64, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_potrf, potrf, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_trsm, trsm, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
+        const size_t xb = std::max<int64_t>(p->xsize, 1) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
+        if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
+            hipMalloc((void**)&p->d_info, sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+        p->bytes_device += xb + vb + sizeof(int);
+    } while (0);
+    if (rc) { sf_chol_plan_destroy(p); return rc; }
+    *out = p;
+    return SF_OK;
+}
+
+int sf_chol_plan_set_values(sf_chol_plan* p, const sf_float* Lx) {
+    if (!p || (!Lx && p->nnz > 0)) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->nnz > 0) HIP_TRY(hipMemcpyAsync(p->d_Lx, Lx, p->nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->values_set = true;
+    return SF_OK;
+}
+
+int sf_chol_plan_sync(sf_chol_plan* p) {
+    if (!p) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int info = 0;
+    HIP_TRY(hipMemcpy(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_ms = ms;
+    p->last_status = info ? SF_ERR_NOT_POSDEF : SF_OK;
+    return p->last_status;
+}
+
+int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
+    if (!p) return SF_ERR_ARG;
+    if (!p->values_set) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = p->stream;
+    std::vector<hipEvent_t> evs;
+    auto mark = [&]() {
+        if (!p->profiling) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); evs.push_back(e); }
+    };
+
+    HIP_TRY(hipEventRecord(p->ev0, st));
+    HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), st));
+    if (p->xsize > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, p->xsize * sizeof(double), st));
+    sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                           p->d_Lsi, p->d_Lsxp, p->d_Lsx, st);
+    mark();
+    std::vector<int> kinds;
+    for (const Launch& L : p->launches) {
+        switch (L.kind) {
+            case 0: sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st); break;
+            case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
+            case 2: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, L.count, 0, p->d_Lsx, p->d_Lsi, st); break;
+            case 3: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, L.count, 1, p->d_Lsx, p->d_Lsi, st); break;
+        }
+        if (p->profiling) { kinds.push_back(L.kind); mark(); }
+    }
+    HIP_TRY(hipEventRecord(p->ev1, st));
+    HIP_TRY(hipGetLastError());
+    if (p->profiling) {
+        HIP_TRY(hipStreamSynchronize(st));
+        p->last_load_ms = p->last_panel_ms = p->last_update_ms = 0;
+        float ms = 0;
+        if (!evs.empty() && hipEventElapsedTime(&ms, p->ev0, evs[0]) == hipSuccess) p->last_load_ms = ms;
+        for (size_t k = 0; k + 1 < evs.size(); ++k) {
+            if (hipEventElapsedTime(&ms, evs[k], evs[k + 1]) != hipSuccess) continue;
+            if (kinds[k] == 3) p->last_update_ms += ms; else p->last_panel_ms += ms;
+        }
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    }
+    if (sync) return sf_chol_plan_sync(p);
+    return SF_OK;
+}
+
+int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
+    if (!p || (!Lsx && p->xsize > 0)) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->xsize > 0) HIP_TRY(hipMemcpy(Lsx, p->d_Lsx, p->xsize * sizeof(double), hipMemcpyDeviceToHost));
+    return SF_OK;
+}
+
+void* sf_chol_plan_factor_device_ptr(sf_chol_plan* p) { return p ? (void*)p->d_Lsx : nullptr; }
+
+int sf_chol_plan_set_profiling(sf_chol_plan* p, int on) {
+    if (!p) return SF_ERR_ARG;
+    p->profiling = on != 0;
+    return SF_OK;
+}
+
+double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
+    if (!p || !name) return -1;
+    const std::string k(name);
+    if (k == "levels") return p->nlevels;
+    if (k == "launches") return (double)p->launches.size();
+    if (k == "gemm_tasks") return (double)p->n_gemm_tasks;
+    if (k == "update_pairs") return (double)p->n_pairs;
+    if (k == "flops_exec") return p->flops_exec;
+    if (k == "flops_update") return p->flops_update;
+    if (k == "flops_panel_gemm") return p->flops_panel_gemm;
+    if (k == "scatter_elems") return p->scatter_elems;
+    if (k == "bytes_device") return (double)p->bytes_device;
+    if (k == "last_ms") return p->last_ms;
+    if (k == "last_load_ms") return p->last_load_ms;
+    if (k == "last_panel_ms") return p->last_panel_ms;
+    if (k == "last_update_ms") return p->last_update_ms;
+    return -1;
+}
+
+int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host) {
+    (void)p; (void)b_host; (void)x_host;
+    return SF_ERR_ARG;   // device solve: not built yet; host solve is SparseFrame_solve_supernodal
+}
+
+// ---------------------------------------------------------------------------------------------------
+// struct-based entry points of the device side
+// ---------------------------------------------------------------------------------------------------
+struct gpu_info_struct {
+    int gpuIndex_physical;
+    size_t devMemSize;
+};
+
+int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {
+    if (!common || !list) return 1;
+    int ndev = sf_device_count();
+    common->numGPU_physical = ndev;
+    common->numGPU = ndev;       // one handler per device; no virtual-GPU splitting (reference C:36-41)
+    common->numCPU = 0;          // the numeric phase has no CPU worker
+    common->minDevMemSize = 0;
+    common->minHostMemSize = 0;
+    *list = (struct gpu_info_struct*)calloc(ndev > 0 ? ndev : 1, sizeof(struct gpu_info_struct));
+    if (!*list) return 1;
+    size_t min_mem = (size_t)-1;
+    for (int d = 0; d < ndev; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+        (*list)[d].gpuIndex_physical = d;
+        (*list)[d].devMemSize = prop.totalGlobalMem;
+        min_mem = std::min(min_mem, (size_t)prop.totalGlobalMem);
+    }
+    if (ndev > 0 && min_mem != (size_t)-1) {
+        // the reference's slot formula (C:82-87, C:199) with its numSplit = max(4 / numGPU, 1)
+        const int numSplit = std::max(4 / ndev, 1);
+        size_t m = (size_t)(((double)min_mem - 64.0 * (0x400 * 0x400)) * 0.9);
+        m /= numSplit;
+        m /= 8;
+        m -= m % (0x400 * 0x400);
+        common->devSlotSize = m;
+        common->minDevMemSize = m * 8;
+    } else {
+        const char* env = getenv("SF_DEVSLOT");
+        common->devSlotSize = env ? (size_t)strtoull(env, nullptr, 10) : ((size_t)1 << 30);
+    }
+    return 0;
+}
+
+int SparseFrame_free_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {
+    if (!list || !*list) return 1;
+    free(*list);
+    *list = nullptr;
+    if (common) common->numGPU = 0;
+    return 0;
+}
+
+int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct gpu_info_struct* list,
+                                     struct matrix_info_struct* mi) {
+    if (!common || !mi || !mi->Lsx) return SF_ERR_ARG;
+    if (common->numGPU <= 0 || !list) {
+        fprintf(stderr, "[sparseframe-hip] SparseFrame_factorize: no GPU handler (numGPU = %d); no CPU fallback\n", common->numGPU);
+        return SF_ERR_NO_DEVICE;
+    }
+    sf_chol_plan* plan = nullptr;
+    int rc = sf_chol_plan_create(&plan, list[0].gpuIndex_physical, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap,
+                                 mi->Lsip, mi->Lsi, mi->Lsxp, mi->Lp, mi->Li);
+    if (rc) return rc;
+    rc = sf_chol_plan_set_values(plan, mi->Lx);
+    if (!rc) rc = sf_chol_plan_factorize(plan, 1);
+    int rc2 = sf_chol_plan_get_factor(plan, mi->Lsx);
+    sf_chol_plan_destroy(plan);
+    return rc ? rc : rc2;
+}
+
+int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {
+    struct timespec a, b;
+    clock_gettime(CLOCK_REALTIME, &a);
+    const int rc = SparseFrame_factorize_supernodal(common, list, mi);
+    clock_gettime(CLOCK_REALTIME, &b);
+    if (mi) mi->factorizeTime = (b.tv_sec - a.tv_sec) + (b.tv_nsec - a.tv_nsec) / 1.0e9;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Device task descriptors and kernel launchers for the supernodal Cholesky numeric phase (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace sf {
+
+constexpr int NB = 64;          // diagonal block size of the in-panel right-looking factorization
+constexpr int TRSM_ROWS = 256;  // rows per TRSM workgroup (one row per lane)
+constexpr int GEMM_BM = 128;    // tile extent along ci (target rows; contiguous in memory)
+constexpr int GEMM_BN = 128;    // tile extent along cj (target columns)
+constexpr int GEMM_BK = 16;
+
+// One C -= Y * X^T problem on rows of ONE source panel (column-major, leading dimension lda):
+//   C[ci][cj] = sum_k src[y_off + ci + k*lda] * src[x_off + cj + k*lda],   0<=ci<M, 0<=cj<N, 0<=k<K
+// only elements with ci >= cj are produced (lower trapezoid).
+// mode 0 (panel):   target = Lsx[c_off + ci + cj*ldc], plain read-modify-write (tile owned by one workgroup)
+// mode 1 (scatter): target = Lsx[c_off + rowmap(ci) + colmap(cj)*ldc] with the relative map of the
+//                   source rows Lsi[src_rows + .] inside the target supernode's row list, fp64 atomic add.
+struct GemmProb {
+    int64_t y_off;      // doubles, into Lsx
+    int64_t x_off;
+    int64_t c_off;
+    int64_t src_rows;   // index into Lsi of the source row id of ci = 0 (scatter mode)
+    int64_t tgt_rows;   // index into Lsi of the target supernode's first below-diagonal row
+    int32_t lda, ldc;
+    int32_t M, N, K;
+    int32_t tgt_first_col;  // Super[a]
+    int32_t tgt_nscol;
+    int32_t tgt_nbelow;     // nsrow_a - nscol_a
+};
+
+struct GemmTask {   // one 128x128 tile
+    int32_t prob;
+    uint16_t tm, tn;    // tile coordinates along ci / cj
+};
+
+struct PotrfTask {  // factor the b x b diagonal block at (diag, diag) of a panel
+    int64_t panel;      // doubles, into Lsx
+    int32_t ld, diag, b;
+    int32_t pad;
+};
+
+struct TrsmTask {   // rows [row0, row0+nrows) of panel columns [diag, diag+b) <- X * D^{-T}
+    int64_t panel;
+    int32_t ld, diag, b;
+    int32_t row0, nrows;
+    int32_t pad;
+};
+
+void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
+                        const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
+                        const int64_t* Lsxp, double* Lsx, hipStream_t st);
+void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st);
+void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
+void launch_gemm(const GemmProb* probs, const GemmTask* tasks, int ntasks, int mode, double* Lsx,
+                 const int32_t* Lsi, hipStream_t st);
+
+// device-side supernodal triangular solves (one launch per level of the supernodal tree)
+struct SolveTask {
+    int64_t panel;      // doubles
+    int64_t rows;       // index into Lsi
+    int32_t nscol, nsrow;
+};
+void launch_solve_fwd(const SolveTask* tasks, int ntasks, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
+void launch_solve_bwd(const SolveTask* tasks, int ntasks, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
+
+}  // namespace sf

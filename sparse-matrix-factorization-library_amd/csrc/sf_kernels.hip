@@ -1,0 +1,323 @@
+// Hand-written gfx950 (CDNA4) kernels of the supernodal Cholesky numeric phase.
+//
+//   k_load_panels  : reference SparseFrame_loadA  (Cholesky/Source/SparseFrame.c:1998-2028) for ALL supernodes
+//                    in one launch; the inverse row map (createMap, cuda_kernel.cu:22-30) is replaced by a
+//                    binary search in the supernode's sorted row list.
+//   k_potrf_block  : dpotrf_('L') on one <=64x64 diagonal block held in LDS       (C:2135, C:2766)
+//   k_trsm_block   : dtrsm_('R','L','C','N') of a row tile against that block     (C:2142, C:2773)
+//   k_gemm<mode>   : fp64 MFMA (v_mfma_f64_16x16x4_f64) C -= Y X^T on LDS-staged panels
+//       mode 0 : in-panel trailing update (the reference's blocked potrf SYRK/GEMM, C:2854-2863)
+//       mode 1 : Schur-complement update of an ancestor panel: dsyrk+dgemm (C:2061-2070) with the
+//                relative map (createRelativeMap, cuda_kernel.cu:42-50) built in the prologue and the
+//                mapped scatter-subtract (mappedSubtract, cuda_kernel.cu:62-124; CPU loop C:2073-2086)
+//                fused into the epilogue as native global_atomic_add_f64, lower trapezoid only.
+//
+// Wavefronts are 64 wide; all tilings below are written for that.
+#include "sf_kernels.h"
+
+namespace sf {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// position of `key` in the ascending array a[0..n); key is known to be present
+__device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, int n, int32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// assemble: one lane per matrix column; A[(j-Super[s])*nsrow + pos(i)] = Lx[p]
+// The panels were zeroed by a memset on the same stream.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_load_panels(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, const double* __restrict__ Lx, int32_t n,
+              const int32_t* __restrict__ Super, const int32_t* __restrict__ SuperMap,
+              const int64_t* __restrict__ Lsip, const int32_t* __restrict__ Lsi,
+              const int64_t* __restrict__ Lsxp, double* __restrict__ Lsx) {
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t s = SuperMap[j];
+    const int32_t c0 = Super[s], c1 = Super[s + 1];
+    const int64_t r0 = Lsip[s];
+    const int32_t nsrow = (int32_t)(Lsip[s + 1] - r0);
+    const int32_t nscol = c1 - c0;
+    double* col = Lsx + Lsxp[s] + (int64_t)(j - c0) * nsrow;
+    const int32_t* below = Lsi + r0 + nscol;
+    for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) {
+        const int32_t i = Li[p];
+        const int32_t si = (i < c1) ? (i - c0) : nscol + lower_bound_i32(below, nsrow - nscol, i);
+        col[si] = Lx[p];
+    }
+}
+
+void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
+                        const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
+                        const int64_t* Lsxp, double* Lsx, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_load_panels, dim3((n + 255) / 256), dim3(256), 0, st,
+                       Lp, Li, Lx, n, Super, SuperMap, Lsip, Lsi, Lsxp, Lsx);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cholesky of a b x b (b <= 64) diagonal block, lower, in LDS.  One workgroup of 256 lanes per block.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_potrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ info) {
+    __shared__ double D[NB][NB + 1];   // D[col][row]
+    const PotrfTask t = tasks[blockIdx.x];
+    double* A = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
+    const int b = t.b;
+    const int tid = threadIdx.x;
+
+    for (int e = tid; e < b * NB; e += 256) {
+        const int c = e / NB, r = e % NB;
+        if (r < b) D[c][r] = (r >= c) ? A[r + (int64_t)c * t.ld] : 0.0;
+    }
+    __syncthreads();
+
+    for (int j = 0; j < b; ++j) {
+        const double djj = D[j][j];
+        if (tid == 0 && !(djj > 0.0)) atomicExch(info, 1);   // not positive definite (also catches NaN)
+        const double d = sqrt(djj);
+        const double rinv = 1.0 / d;
+        __syncthreads();
+        // scale column j
+        if (tid < b - j) {
+            const int r = j + tid;
+            D[j][r] = (tid == 0) ? d : D[j][r] * rinv;
+        }
+        __syncthreads();
+        // trailing rank-1 update of the lower triangle: (r, c), j < c <= r < b
+        const int m = b - j - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int c = j + 1 + e / m, r = j + 1 + e % m;
+            if (r >= c) D[c][r] -= D[j][r] * D[j][c];
+        }
+        __syncthreads();
+    }
+
+    for (int e = tid; e < b * NB; e += 256) {
+        const int c = e / NB, r = e % NB;
+        if (r < b && r >= c) A[r + (int64_t)c * t.ld] = D[c][r];
+    }
+}
+
+void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st) {
+    if (ntasks <= 0) return;
+    hipLaunchKernelGGL(k_potrf_block, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, info);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// X <- X * D^{-T} for a tile of rows, D = lower-triangular b x b block already factored.
+// One row per lane (rows are contiguous in memory: coalesced 8-byte accesses per column).
+// The row is solved 8 columns at a time: the 8 running sums live in registers, the contributions of
+// the columns already solved are re-read from the panel (the lane's own earlier stores, L2-resident)
+// and D is broadcast from LDS, transposed so that the 8 multipliers of one k are 64 contiguous bytes.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TRSM_ROWS)
+k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx) {
+    __shared__ __attribute__((aligned(16))) double Dt[NB][NB];   // Dt[k][j] = L(j,k) for k < j, else 0
+    __shared__ double Dinv[NB];
+    const TrsmTask t = tasks[blockIdx.x];
+    const double* Dg = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
+    const int b = t.b;
+    const int tid = threadIdx.x;
+
+    for (int e = tid; e < NB * NB; e += TRSM_ROWS) {
+        const int k = e / NB, j = e % NB;   // column k, row j of the block: coalesced along j
+        Dt[k][j] = (j < b && k < j) ? Dg[j + (int64_t)k * t.ld] : 0.0;
+    }
+    if (tid < NB) Dinv[tid] = (tid < b) ? 1.0 / Dg[tid + (int64_t)tid * t.ld] : 1.0;
+    __syncthreads();
+
+    if (tid >= t.nrows) return;
+    double* X = Lsx + t.panel + t.row0 + tid + (int64_t)t.diag * t.ld;
+    const int64_t ld = t.ld;
+
+    for (int jb = 0; jb < b; jb += 8) {
+        double acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = (jb + u < b) ? X[(jb + u) * ld] : 0.0;
+        for (int k = 0; k < jb; ++k) {
+            const double xk = X[k * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] -= xk * Dt[k][jb + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int v = 0; v < u; ++v) acc[u] -= acc[v] * Dt[jb + v][jb + u];
+            acc[u] *= Dinv[jb + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (jb + u < b) X[(jb + u) * ld] = acc[u];
+    }
+}
+
+void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st) {
+    if (ntasks <= 0) return;
+    hipLaunchKernelGGL(k_trsm_block, dim3(ntasks), dim3(TRSM_ROWS), 0, st, tasks, Lsx);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp64 MFMA GEMM  C[ci][cj] -= sum_k Y[ci][k] X[cj][k]   (lower trapezoid ci >= cj)
+//
+// Workgroup = 4 waves (2 x 2), tile 128 (ci) x 128 (cj), K step 16, double-buffered LDS.
+// Each wave owns a 64 x 64 sub-tile = 4 x 4 MFMA tiles of v_mfma_f64_16x16x4_f64:
+//     A operand (row index of D)  <- X rows (cj)      lane l: X[cj = l&15][k = l>>4]
+//     B operand (col index of D)  <- Y rows (ci)      lane l: Y[ci = l&15][k = l>>4]
+//     D[row = (l>>4) + 4*reg][col = l&15]             (f64 layout: NOT the f32 one)
+// so that the 16 consecutive lanes of a quarter-wave hold 16 consecutive TARGET ROWS (ci), which are
+// contiguous in the column-major target panel: the epilogue's atomics / stores hit 128-byte runs.
+// LDS image of an operand tile: [k][row] with the row stride padded to 144 doubles, which makes the
+// ds_read_b64 fragment reads (16 rows x 2 k per half-wave) hit all 64 banks exactly once.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LDS_LD = GEMM_BM + 16;
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)
+k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks, int ntasks,
+       double* __restrict__ Lsx, const int32_t* __restrict__ Lsi) {
+    __shared__ double Ys[2][GEMM_BK][LDS_LD];
+    __shared__ double Xs[2][GEMM_BK][LDS_LD];
+    __shared__ int32_t rowmap[GEMM_BM];
+    __shared__ int32_t colmap[GEMM_BN];
+
+    // XCD-aware order: workgroups b, b+8, b+16 ... share an XCD (and its L2); give each XCD a
+    // contiguous run of tasks so that tiles of one problem re-use the operand panels from one L2.
+    int task_id;
+    {
+        const int b = blockIdx.x, q = ntasks >> 3, r = ntasks & 7, x = b & 7;
+        task_id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const GemmTask tk = tasks[task_id];
+    const GemmProb pb = probs[tk.prob];
+    const int ci0 = tk.tm * GEMM_BM, cj0 = tk.tn * GEMM_BN;
+    const int M = pb.M, N = pb.N, K = pb.K;
+    const int lda = pb.lda;
+    const double* __restrict__ Yg = Lsx + pb.y_off + ci0;
+    const double* __restrict__ Xg = Lsx + pb.x_off + cj0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    if (MODE == 1) {
+        // relative map of this tile's rows/columns inside the target panel
+        if (tid < GEMM_BM) {
+            const int ci = ci0 + tid;
+            int32_t v = 0;
+            if (ci < M) {
+                const int32_t g = Lsi[pb.src_rows + ci];
+                v = (ci < N) ? (g - pb.tgt_first_col)
+                             : pb.tgt_nscol + lower_bound_i32(Lsi + pb.tgt_rows, pb.tgt_nbelow, g);
+            }
+            rowmap[tid] = v;
+        } else {
+            const int cj = cj0 + (tid - GEMM_BM);
+            colmap[tid - GEMM_BM] = (cj < N) ? (Lsi[pb.src_rows + cj] - pb.tgt_first_col) : 0;
+        }
+    }
+
+    // global -> register staging: lane handles row (tid & 127), k = (tid >> 7) + 2*q, q = 0..7
+    const int lrow = tid & 127, lk0 = tid >> 7;
+    const bool yrow_ok = (ci0 + lrow) < M, xrow_ok = (cj0 + lrow) < N;
+    double ry[8], rx[8];
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + lk0 + 2 * q;
+            const bool kin = k < K;
+            ry[q] = (yrow_ok && kin) ? Yg[lrow + (int64_t)k * lda] : 0.0;
+            rx[q] = (xrow_ok && kin) ? Xg[lrow + (int64_t)k * lda] : 0.0;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            Ys[buf][lk0 + 2 * q][lrow] = ry[q];
+            Xs[buf][lk0 + 2 * q][lrow] = rx[q];
+        }
+    };
+
+    // a wave whose 64x64 quadrant lies entirely outside the lower trapezoid does no MFMA work
+    const int qci0 = ci0 + wm * 64, qcj0 = cj0 + wn * 64;
+    const bool quad_active = (qci0 < M) && (qcj0 < N) && (qci0 + 63 >= qcj0);
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    const int fr = lane & 15, fk = lane >> 4;
+    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
+    load_tile(0);
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        store_tile(buf);
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile((kt + 1) * GEMM_BK);
+        if (quad_active) {
+#pragma unroll
+            for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[t] = Xs[buf][kk * 4 + fk][wn * 64 + t * 16 + fr];
+                    b[t] = Ys[buf][kk * 4 + fk][wm * 64 + t * 16 + fr];
+                }
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+
+    if (!quad_active) return;
+    double* __restrict__ Cg = Lsx + pb.c_off;
+    const int64_t ldc = pb.ldc;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int lci = wm * 64 + tn * 16 + fr;
+            const int ci = ci0 + lci;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lcj = wn * 64 + tm * 16 + fk + 4 * r;
+                const int cj = cj0 + lcj;
+                if (ci < M && cj < N && ci >= cj) {
+                    const double v = acc[tm][tn][r];
+                    if (MODE == 1) {
+                        double* dst = Cg + rowmap[lci] + (int64_t)colmap[lcj] * ldc;
+                        unsafeAtomicAdd(dst, -v);
+                    } else {
+                        double* dst = Cg + ci + (int64_t)cj * ldc;
+                        *dst -= v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+void launch_gemm(const GemmProb* probs, const GemmTask* tasks, int ntasks, int mode, double* Lsx,
+                 const int32_t* Lsi, hipStream_t st) {
+    if (ntasks <= 0) return;
+    if (mode == 1)
+        hipLaunchKernelGGL(k_gemm<1>, dim3(ntasks), dim3(256), 0, st, probs, tasks, ntasks, Lsx, Lsi);
+    else
+        hipLaunchKernelGGL(k_gemm<0>, dim3(ntasks), dim3(256), 0, st, probs, tasks, ntasks, Lsx, Lsi);
+}
+
+}  // namespace sf

@@ -1,0 +1,519 @@
+// Host-side symbolic analysis for the supernodal Cholesky path.
+//
+// This is the caller side of the hot path: it produces every integer input of the numeric
+// factorization.  The semantics (and therefore every integer output, bit for bit, for a given
+// Perm and devSlotSize) follow the reference's SparseFrame_analyze pipeline:
+//   perm            Cholesky/Source/SparseFrame.c:956-1066
+//   etree           :1068-1127
+//   postorder       :1129-1236   (plain, then weighted by ColCount :1967)
+//   colcount        :1238-1352
+//   analyze_supernodal :1354-1914 (fundamental supernodes, relaxed amalgamation,
+//                    Lsi row structure, csize, stages, leaf queue, slot offsets)
+// The code is organised differently (separate passes over std::vector, no shared workspace
+// aliasing) but each pass is written to reproduce the reference's tie-breaking exactly.
+#include "sf_symbolic.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace sf {
+
+namespace {
+
+// reference parameter.h:31-46
+bool relax_allowed(Long ncol, double zero_rate) {
+    static const Long col_thr[3] = {16, 64, 256};
+    static const double rate_thr[3] = {0.8, 0.1, 0.05};
+    for (int k = 2; k >= 0; --k)
+        if (ncol > col_thr[k] && zero_rate > rate_thr[k]) return false;
+    return true;
+}
+
+// lower(P A P^T) by column (column = min(i,j), row = max(i,j)) and its transpose.
+// Entry order inside a column follows the traversal order of C:1036-1063.
+void build_triangles(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+                     const std::vector<Long>& Perm, Symbolic& S) {
+    std::vector<Long> Pinv(n, -1);
+    for (Long j = 0; j < n; ++j)
+        if (Perm[j] >= 0) Pinv[Perm[j]] = j;
+
+    const Long nz = Cp[n];
+    S.Lp.assign(n + 1, 0);
+    S.LTp.assign(n + 1, 0);
+    S.Li.resize(nz);  S.Lx.resize(nz);
+    S.LTi.resize(nz); S.LTx.resize(nz);
+
+    for (Long j = 0; j < n; ++j) {
+        const Long jold = Perm[j];
+        if (jold < 0) continue;
+        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
+            const Long i = Pinv[Ci[p]];
+            S.Lp[std::min(i, j) + 1]++;
+            S.LTp[std::max(i, j) + 1]++;
+        }
+    }
+    for (Long j = 0; j < n; ++j) {
+        S.Lp[j + 1] += S.Lp[j];
+        S.LTp[j + 1] += S.LTp[j];
+    }
+    std::vector<Long> lnext(S.Lp.begin(), S.Lp.end() - 1), tnext(S.LTp.begin(), S.LTp.end() - 1);
+    for (Long j = 0; j < n; ++j) {
+        const Long jold = Perm[j];
+        if (jold < 0) continue;
+        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
+            const Long i = Pinv[Ci[p]];
+            const Long lo = std::min(i, j), hi = std::max(i, j);
+            const Long lp = lnext[lo]++;
+            S.Li[lp] = hi;
+            S.Lx[lp] = Cx ? Cx[p] : 0.0;
+            const Long tp = tnext[hi]++;
+            S.LTi[tp] = lo;
+            S.LTx[tp] = Cx ? Cx[p] : 0.0;
+        }
+    }
+}
+
+// Liu's elimination tree with path compression over the rows of L (columns of L^T).
+void elimination_tree(const Symbolic& S, std::vector<Long>& Parent) {
+    const Long n = S.n;
+    Parent.assign(n, -1);
+    std::vector<Long> Anc(n, -1);
+    for (Long j = 0; j < n; ++j) {
+        for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) {
+            Long i = S.LTi[p];
+            while (i >= 0 && i < j) {
+                const Long a = Anc[i];
+                Anc[i] = j;
+                if (a < 0) { Parent[i] = j; break; }
+                if (a == j) break;
+                i = a;
+            }
+        }
+    }
+}
+
+// Postorder of the forest.  With weights (ColCount), children are visited in ascending weight,
+// ties in ascending index; without, in ascending index.  Roots in ascending index.
+void postorder(const std::vector<Long>& Parent, const std::vector<Long>* Weight, std::vector<Long>& Post) {
+    const Long n = (Long)Parent.size();
+    std::vector<Long> Head(n, -1), Next(n, -1);
+    if (!Weight) {
+        for (Long j = n - 1; j >= 0; --j) {
+            const Long p = Parent[j];
+            if (p >= 0 && p < n) { Next[j] = Head[p]; Head[p] = j; }
+        }
+    } else {
+        // bucket by weight; the reference's buckets are [0,n) (C:1175-1199).  A weight of n (first
+        // column dense, not a root) would fall outside them there; we keep a bucket for it.
+        std::vector<Long> Bucket(n + 1, -1);
+        for (Long j = 0; j < n; ++j) {
+            if (Parent[j] >= 0) {
+                const Long w = (*Weight)[j];
+                Next[j] = Bucket[w];
+                Bucket[w] = j;
+            }
+        }
+        for (Long w = n; w >= 0; --w) {
+            Long j = Bucket[w];
+            while (j >= 0) {
+                const Long jn = Next[j];
+                const Long p = Parent[j];
+                Next[j] = Head[p];
+                Head[p] = j;
+                j = jn;
+            }
+        }
+    }
+    std::vector<Long> Stack;
+    Stack.reserve(n);
+    for (Long j = n - 1; j >= 0; --j)
+        if (Parent[j] < 0) Stack.push_back(j);
+    Post.assign(n, -1);
+    Long k = 0;
+    while (!Stack.empty()) {
+        const Long j = Stack.back();
+        const Long c = Head[j];
+        if (c >= 0) {
+            Head[j] = Next[c];
+            Stack.push_back(c);
+        } else {
+            Stack.pop_back();
+            Post[k++] = j;
+        }
+    }
+}
+
+// Column counts of L by the skeleton-leaf / disjoint-set method (C:1238-1352).
+void column_counts(const Symbolic& S, const std::vector<Long>& Parent, const std::vector<Long>& Post,
+                   std::vector<Long>& Count) {
+    const Long n = S.n;
+    std::vector<Long> First(n, -1), Set(n), PrevLeaf(n), PrevNbr(n, -1);
+    Count.assign(n, 0);
+    for (Long k = 0; k < n; ++k) {
+        for (Long p = Post[k]; p >= 0 && First[p] < 0; p = Parent[p]) First[p] = k;
+    }
+    for (Long j = 0; j < n; ++j) { Set[j] = j; PrevLeaf[j] = j; }
+    for (Long k = 0; k < n; ++k) {
+        const Long j = Post[k];
+        PrevNbr[j] = k;
+        for (Long p = S.Lp[j]; p < S.Lp[j + 1]; ++p) {
+            const Long i = S.Li[p];
+            if (i <= j) continue;
+            if (First[j] > PrevNbr[i]) {
+                const Long pl = PrevLeaf[i];
+                Long r = pl;
+                while (r != Set[r]) r = Set[r];
+                for (Long s = pl; s != r;) { const Long t = Set[s]; Set[s] = r; s = t; }
+                Count[j]++;
+                Count[r]--;
+                PrevLeaf[i] = j;
+            }
+            PrevNbr[i] = k;
+        }
+        Set[j] = Parent[j];
+    }
+    for (Long k = 0; k < n; ++k) {
+        const Long j = Post[k];
+        if (Parent[j] >= 0) Count[Parent[j]] += Count[j];
+    }
+    for (Long j = 0; j < n; ++j) Count[j]++;
+}
+
+inline bool fits_slot(Long ncol, Long nrow, size_t slot) {
+    // (ncol*nrow)*sizeof(Float) + nrow*sizeof(Long) <= devSlotSize, in size_t arithmetic (C:1482-1484)
+    return (size_t)ncol * (size_t)nrow * sizeof(double) + (size_t)nrow * sizeof(Long) <= slot;
+}
+
+}  // namespace
+
+int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+                     const Long* perm, size_t devSlotSize, Symbolic& S) {
+    if (n < 0 || !Cp || (n > 0 && !Ci)) return 1;
+    S = Symbolic();
+    S.n = n;
+    S.devSlotSize = devSlotSize;
+
+    std::vector<Long> Perm(n);
+    for (Long j = 0; j < n; ++j) Perm[j] = perm ? perm[j] : j;
+    if (perm) {  // must be a permutation
+        std::vector<char> seen(n, 0);
+        for (Long j = 0; j < n; ++j) {
+            if (Perm[j] < 0 || Perm[j] >= n || seen[Perm[j]]) return 1;
+            seen[Perm[j]] = 1;
+        }
+    }
+    for (Long p = 0; p < Cp[n]; ++p)
+        if (Ci[p] < 0 || Ci[p] >= n) return 1;
+
+    build_triangles(n, Cp, Ci, Cx, Perm, S);
+
+    std::vector<Long> Parent, Post, Count;
+    elimination_tree(S, Parent);
+    postorder(Parent, nullptr, Post);
+    column_counts(S, Parent, Post, Count);
+    postorder(Parent, &Count, Post);
+
+    S.Post = Post;
+    S.Parent0 = Parent;
+    S.ColCount0 = Count;
+
+    // ---- renumber into the weighted postorder and rebuild the triangles (C:1429-1447) ----
+    std::vector<Long> InvPost(n);
+    for (Long k = 0; k < n; ++k) InvPost[Post[k]] = k;
+    S.Perm.resize(n); S.Parent.resize(n); S.ColCount.resize(n);
+    for (Long k = 0; k < n; ++k) {
+        const Long old = Post[k];
+        S.Perm[k] = Perm[old];
+        S.Parent[k] = Parent[old] < 0 ? -1 : InvPost[Parent[old]];
+        S.ColCount[k] = Count[old];
+    }
+    build_triangles(n, Cp, Ci, Cx, S.Perm, S);
+
+    const std::vector<Long>& Par = S.Parent;
+    const std::vector<Long>& CC = S.ColCount;
+
+    // ---- fundamental supernodes, capped by the slot size (C:1462-1522) ----
+    std::vector<Long> Nchild(n, 0);
+    for (Long j = 0; j < n; ++j)
+        if (Par[j] >= 0 && Par[j] < n) Nchild[Par[j]]++;
+
+    std::vector<Long> Fsuper;  // first column of each fundamental supernode
+    if (n > 0) Fsuper.push_back(0);
+    for (Long j = 1; j < n; ++j) {
+        const Long first = Fsuper.back();
+        const bool chain_breaks = (Par[j - 1] != j) || (CC[j - 1] != CC[j] + 1) || (Nchild[j] > 1);
+        if (chain_breaks || !fits_slot(j - first + 1, CC[first], devSlotSize)) Fsuper.push_back(j);
+    }
+    const Long nf = (Long)Fsuper.size();
+    Fsuper.push_back(n);
+    S.nfsuper = nf;
+
+    std::vector<Long> Nscol(nf), Scc(nf), Fmap(n), Fparent(nf);
+    for (Long s = 0; s < nf; ++s) {
+        Nscol[s] = Fsuper[s + 1] - Fsuper[s];
+        Scc[s] = CC[Fsuper[s]];
+        for (Long j = Fsuper[s]; j < Fsuper[s + 1]; ++j) Fmap[j] = s;
+    }
+    for (Long s = 0; s < nf; ++s) {
+        const Long p = Par[Fsuper[s + 1] - 1];
+        Fparent[s] = p < 0 ? -1 : Fmap[p];
+    }
+
+    // ---- relaxed amalgamation of a last child into its parent (C:1524-1622) ----
+    std::vector<Long> Merge(nf), Nsz(nf, 0);
+    for (Long s = 0; s < nf; ++s) Merge[s] = s;
+    for (Long s = nf - 2; s >= 0; --s) {
+        const Long sp = Fparent[s];
+        if (sp < 0 || sp >= nf || Merge[s + 1] != Merge[sp]) continue;
+        const Long g = Merge[sp];
+        const Long s_n = Nscol[s], p_n = Nscol[g], s_c = Scc[s], p_c = Scc[g];
+        if (!fits_slot(s_n + p_n, s_n + p_c, devSlotSize)) continue;
+        const Long total_zero = Nsz[s] + Nsz[g] + s_n * (s_n + p_c - s_c);
+        const Long tot = s_n + p_n;
+        const Long denom = tot * (tot + 1) / 2 + tot * (p_c - p_n);
+        if (relax_allowed(tot, (double)total_zero / (double)denom)) {
+            Nscol[g] = tot;
+            Scc[g] = s_n + p_c;
+            Nsz[g] = total_zero;
+            Merge[s] = g;
+        }
+    }
+
+    // compact: a merged group is numbered by its representative, its first column is the first
+    // column of its earliest member (members are consecutive, ending at the representative)
+    S.Super.clear();
+    std::vector<Long> Gncol, Gcc;
+    S.Super.push_back(0);
+    for (Long s = 0; s < nf; ++s) {
+        if (Merge[s] == s) {
+            S.Super.push_back(Fsuper[s + 1]);
+            Gncol.push_back(Nscol[s]);
+            Gcc.push_back(Scc[s]);
+        }
+    }
+    const Long ns = (Long)Gncol.size();
+    S.nsuper = ns;
+    if (n == 0) { S.Super.assign(1, 0); }
+    S.Super[ns] = n;
+
+    S.SuperMap.assign(n, 0);
+    for (Long s = 0; s < ns; ++s)
+        for (Long j = S.Super[s]; j < S.Super[s + 1]; ++j) S.SuperMap[j] = s;
+    S.Sparent.assign(ns, -1);
+    for (Long s = 0; s < ns; ++s) {
+        const Long p = Par[S.Super[s + 1] - 1];
+        S.Sparent[s] = p < 0 ? -1 : S.SuperMap[p];
+    }
+
+    // ---- pointers (C:1632-1645) ----
+    S.Lsip.assign(ns + 1, 0);
+    S.Lsxp.assign(ns + 1, 0);
+    for (Long s = 0; s < ns; ++s) {
+        S.Lsip[s + 1] = S.Lsip[s] + Gcc[s];
+        S.Lsxp[s + 1] = S.Lsxp[s] + Gncol[s] * Gcc[s];
+    }
+    S.isize = S.Lsip[ns];
+    S.xsize = S.Lsxp[ns];
+
+    // ---- row structure: own columns, then every row j that reaches the supernode through
+    //      the supernodal tree from the supernode of a nonzero (j,i), i<=j (C:1660-1692) ----
+    S.Lsi.assign(S.isize, -1);
+    {
+        std::vector<Long> fill(S.Lsip.begin(), S.Lsip.end() - 1), Marker(ns);
+        for (Long s = 0; s < ns; ++s) {
+            Marker[s] = S.Super[s + 1];
+            for (Long k = S.Super[s]; k < S.Super[s + 1]; ++k) S.Lsi[fill[s]++] = k;
+        }
+        for (Long j = 0; j < n; ++j) {
+            for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) {
+                for (Long d = S.SuperMap[S.LTi[p]]; d >= 0 && Marker[d] <= j; d = S.Sparent[d]) {
+                    if (fill[d] >= S.Lsip[d + 1]) return 2;  // count mismatch: symbolic inconsistency
+                    S.Lsi[fill[d]++] = j;
+                    Marker[d] = j + 1;
+                }
+            }
+        }
+        for (Long s = 0; s < ns; ++s)
+            if (fill[s] != S.Lsip[s + 1]) return 2;
+    }
+
+    // ---- csize: largest update block any descendant->ancestor pair needs (C:1694-1719) ----
+    S.csize = 0;
+    for (Long s = 0; s < ns; ++s) {
+        const Long nscol = S.Super[s + 1] - S.Super[s];
+        const Long nsrow = S.Lsip[s + 1] - S.Lsip[s];
+        if (nscol >= nsrow) continue;
+        const Long* rows = &S.Lsi[S.Lsip[s]];
+        Long start = nscol;
+        Long owner = S.SuperMap[rows[nscol]];
+        for (Long si = nscol; si < nsrow; ++si) {
+            const Long o = S.SuperMap[rows[si]];
+            if (o != owner) {
+                S.csize = std::max(S.csize, (si - start) * (nsrow - start));
+                start = si;
+                owner = o;
+            }
+        }
+        S.csize = std::max(S.csize, (nsrow - start) * (nsrow - start));
+    }
+
+    // ---- stages: greedy root-to-leaf packing into slot-sized groups (C:1721-1846) ----
+    {
+        std::vector<Long> Head(std::max<Long>(ns, 1), -1), Next(std::max<Long>(ns, 1), -1);
+        std::vector<Long> Asz(std::max<Long>(ns, 1), 0), Msz(std::max<Long>(ns, 1), 0);
+        S.ST_Map.assign(ns, -1);
+        Long nstage = ns > 0 ? 1 : 0;
+        auto stage_fits = [&](Long st, Long a, Long m) {
+            return (size_t)(Asz[st] + a) * sizeof(double) + (size_t)(Msz[st] + m) * sizeof(Long) <= devSlotSize;
+        };
+        for (Long s = ns - 1; s >= 0; --s) {
+            const Long a = (S.Super[s + 1] - S.Super[s]) * (S.Lsip[s + 1] - S.Lsip[s]);
+            const Long m = S.Lsip[s + 1] - S.Lsip[s];
+            Long st;
+            const Long sp = S.Sparent[s];
+            if (sp >= 0) {
+                st = S.ST_Map[sp];
+                if (stage_fits(st, a, m)) {
+                    S.ST_Map[s] = st; Asz[st] += a; Msz[st] += m;
+                    continue;
+                }
+                st = Head[S.ST_Map[sp]];
+            } else {
+                st = 0;
+            }
+            while (st >= 0) {
+                if (stage_fits(st, a, m)) {
+                    S.ST_Map[s] = st; Asz[st] += a; Msz[st] += m;
+                    break;
+                }
+                st = Next[st];
+            }
+            if (st < 0) {
+                S.ST_Map[s] = nstage;
+                Asz[nstage] = a;
+                Msz[nstage] = m;
+                if (sp >= 0) {
+                    Next[nstage] = Head[S.ST_Map[sp]];
+                    Head[S.ST_Map[sp]] = nstage;
+                } else {
+                    Next[nstage] = Next[0];
+                    Next[0] = nstage;
+                }
+                nstage++;
+            }
+        }
+        for (Long s = 0; s < ns; ++s) S.ST_Map[s] = nstage - 1 - S.ST_Map[s];
+        S.nstage = nstage;
+        S.ST_Pointer.assign(nstage + 1, 0);
+        S.ST_Index.assign(ns, 0);
+        for (Long s = 0; s < ns; ++s) S.ST_Pointer[S.ST_Map[s] + 1]++;
+        for (Long st = 0; st < nstage; ++st) S.ST_Pointer[st + 1] += S.ST_Pointer[st];
+        std::vector<Long> fill(S.ST_Pointer.begin(), S.ST_Pointer.end() - 1);
+        for (Long s = 0; s < ns; ++s) S.ST_Index[fill[S.ST_Map[s]]++] = s;
+    }
+
+    // ---- leaf queue in stage order (C:1848-1873) ----
+    {
+        std::vector<char> has_child(std::max<Long>(ns, 1), 0);
+        for (Long s = 0; s < ns; ++s) {
+            const Long nscol = S.Super[s + 1] - S.Super[s];
+            const Long nsrow = S.Lsip[s + 1] - S.Lsip[s];
+            if (nscol < nsrow) has_child[S.SuperMap[S.Lsi[S.Lsip[s] + nscol]]] = 1;
+        }
+        S.LeafQueue.assign(ns, -1);
+        S.nsleaf = 0;
+        for (Long k = 0; k < ns; ++k) {
+            const Long s = S.ST_Index[k];
+            if (!has_child[s]) S.LeafQueue[S.nsleaf++] = s;
+        }
+    }
+
+    // ---- byte offsets of each panel / relative map inside its stage's slot (C:1875-1904) ----
+    S.Aoffset.assign(ns, 0);
+    S.Moffset.assign(ns, 0);
+    for (Long st = 0; st < S.nstage; ++st) {
+        size_t asz = 0, msz = 0;
+        for (Long k = S.ST_Pointer[st]; k < S.ST_Pointer[st + 1]; ++k) {
+            const Long s = S.ST_Index[k];
+            const Long nscol = S.Super[s + 1] - S.Super[s];
+            const Long nsrow = S.Lsip[s + 1] - S.Lsip[s];
+            S.Aoffset[s] = (Long)asz;
+            asz += (size_t)(nscol * nsrow) * sizeof(double);
+            S.Moffset[s] = (Long)msz;
+            msz += (size_t)nsrow * sizeof(Long);
+        }
+        for (Long k = S.ST_Pointer[st]; k < S.ST_Pointer[st + 1]; ++k) S.Moffset[S.ST_Index[k]] += (Long)asz;
+    }
+    return 0;
+}
+
+double flops_struct(const Symbolic& S) {
+    double f = 0;
+    for (Long c : S.ColCount0) f += (double)c * (double)c;
+    return f;
+}
+
+double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems) {
+    double fac = 0, upd = 0, sc = 0;
+    for (Long s = 0; s < S.nsuper; ++s) {
+        const double n = (double)(S.Super[s + 1] - S.Super[s]);
+        const Long nsrow = S.Lsip[s + 1] - S.Lsip[s];
+        const double m = (double)nsrow - n;
+        fac += n * n * n / 3.0 + m * n * n;
+        const Long* rows = &S.Lsi[S.Lsip[s]];
+        Long i = (Long)n;
+        while (i < nsrow) {
+            const Long owner = S.SuperMap[rows[i]];
+            Long e = i;
+            while (e < nsrow && S.SuperMap[rows[e]] == owner) ++e;
+            const double dn = (double)(e - i), dm = (double)(nsrow - e);
+            upd += dn * (dn + 1) * n + 2.0 * dm * dn * n;
+            sc += dn * (dn + 1) / 2.0 + dm * dn;
+            i = e;
+        }
+    }
+    if (update_flops) *update_flops = upd;
+    if (scatter_elems) *scatter_elems = sc;
+    return fac + upd;
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometric nested dissection on a regular grid
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Box { Long lo[3], hi[3]; };
+
+void nd_emit(const Box& b, Long nx, Long ny, Long*& out) {
+    for (Long z = b.lo[2]; z < b.hi[2]; ++z)
+        for (Long y = b.lo[1]; y < b.hi[1]; ++y)
+            for (Long x = b.lo[0]; x < b.hi[0]; ++x) *out++ = x + nx * (y + ny * z);
+}
+
+void nd_rec(const Box& b, Long nx, Long ny, Long leaf, Long sepw, Long*& out) {
+    Long len[3];
+    for (int a = 0; a < 3; ++a) len[a] = b.hi[a] - b.lo[a];
+    if (len[0] <= 0 || len[1] <= 0 || len[2] <= 0) return;
+    int ax = 0;
+    for (int a = 1; a < 3; ++a)
+        if (len[a] > len[ax]) ax = a;  // longest axis, ties -> lowest axis index
+    if (len[ax] <= leaf || len[ax] < sepw + 2) { nd_emit(b, nx, ny, out); return; }
+    const Long mid = b.lo[ax] + (len[ax] - sepw + 1) / 2;
+    Box l = b, r = b, s = b;
+    l.hi[ax] = mid;
+    s.lo[ax] = mid; s.hi[ax] = mid + sepw;
+    r.lo[ax] = mid + sepw;
+    nd_rec(l, nx, ny, leaf, sepw, out);
+    nd_rec(r, nx, ny, leaf, sepw, out);
+    nd_emit(s, nx, ny, out);
+}
+}  // namespace
+
+int grid_nd_perm(Long nx, Long ny, Long nz, Long leaf, Long sepw, Long* perm) {
+    if (nx <= 0 || ny <= 0 || nz <= 0 || leaf <= 0 || sepw <= 0 || !perm) return 1;
+    Box b{{0, 0, 0}, {nx, ny, nz}};
+    Long* out = perm;
+    nd_rec(b, nx, ny, leaf, sepw, out);
+    return (out - perm) == nx * ny * nz ? 0 : 2;
+}
+
+}  // namespace sf

@@ -1,0 +1,50 @@
+// Internal C++ view of the symbolic analysis result.  Host only.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace sf {
+
+using Long = int64_t;
+
+struct Symbolic {
+    Long n = 0;
+    size_t devSlotSize = 0;
+
+    // permuted lower triangle (by column) and its transpose; reference C:956-1066
+    std::vector<Long> Lp, Li, LTp, LTi;
+    std::vector<double> Lx, LTx;
+
+    std::vector<Long> Perm;      // final (post-order composed), C:1438
+    std::vector<Long> Parent;    // final numbering, C:1439
+    std::vector<Long> ColCount;  // final numbering, C:1440
+    std::vector<Long> Post;      // the second (weighted) postorder, C:1967
+    std::vector<Long> Parent0;   // etree before renumbering
+    std::vector<Long> ColCount0; // column counts before renumbering
+
+    Long nfsuper = 0, nsuper = 0;
+    std::vector<Long> Super, SuperMap, Sparent;
+    std::vector<Long> Lsip, Lsxp, Lsi;
+    Long isize = 0, xsize = 0, csize = 0;
+
+    Long nstage = 0;
+    std::vector<Long> ST_Map, ST_Pointer, ST_Index;
+    std::vector<Long> Aoffset, Moffset;   // bytes, as size_t in the reference
+
+    Long nsleaf = 0;
+    std::vector<Long> LeafQueue;
+};
+
+// Cp/Ci/Cx: one triangle of the symmetric matrix in CSC.  perm may be null (identity).
+// Returns 0 on success.
+int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+                     const Long* perm, size_t devSlotSize, Symbolic& out);
+
+// flop counters
+double flops_struct(const Symbolic& S);
+double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems);
+
+int grid_nd_perm(Long nx, Long ny, Long nz, Long leaf, Long sepw, Long* perm);
+
+}  // namespace sf

@@ -1,0 +1,134 @@
+"""Synthetic input matrices of BASELINE.json's configs, as the lower triangle in CSC (what a
+MatrixMarket 'symmetric' file holds and what SparseFrame_compress produces, SparseFrame.c:526-587).
+
+All generators are vectorised numpy and deterministic.  Node numbering of a grid: id = x + nx*(y + ny*z).
+"""
+import numpy as np
+
+
+def _csc_from_coo(n, rows, cols, vals):
+    """column-major compress; entry order inside a column = input order (stable), like the
+    reference's counting sort (SparseFrame.c:560-576)."""
+    order = np.argsort(cols, kind="stable")
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    Cp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(Cp, cols + 1, 1)
+    Cp = np.cumsum(Cp)
+    return Cp, rows.astype(np.int64), vals.astype(np.float64)
+
+
+def laplacian_lower(nx, ny=1, nz=1, diag=None):
+    """(2*dims)-point Laplacian on an nx*ny*nz grid (5-point in 2-D, 7-point in 3-D): lower triangle.
+    diag defaults to 2*dims (4 in 2-D, 6 in 3-D), off-diagonals are -1."""
+    n = nx * ny * nz
+    dims = (nx > 1) + (ny > 1) + (nz > 1)
+    if diag is None:
+        diag = 2.0 * max(dims, 1)
+    idx = np.arange(n, dtype=np.int64)
+    x = idx % nx
+    y = (idx // nx) % ny
+    z = idx // (nx * ny)
+    rows = [idx]
+    cols = [idx]
+    vals = [np.full(n, float(diag))]
+    for mask, off in ((x + 1 < nx, 1), (y + 1 < ny, nx), (z + 1 < nz, nx * ny)):
+        j = idx[mask]
+        rows.append(j + off)     # row > col: lower triangle
+        cols.append(j)
+        vals.append(np.full(j.size, -1.0))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    Cp, Ci, Cx = _csc_from_coo(n, rows, cols, vals)
+    return n, Cp, Ci, Cx
+
+
+def stencil_spd_lower(nx, ny, radius=2, seed=12345):
+    """BASELINE config 3 stand-in: 2-D grid, all neighbours within Chebyshev... no: within the
+    radius-2 *diamond plus box corners* 21-point stencil (|dx|,|dy| <= 2 without the 4 far corners),
+    off-diagonals U(-1,0), diagonal 1 + sum|offdiag| (strictly diagonally dominant => SPD)."""
+    n = nx * ny
+    rng = np.random.default_rng(seed)
+    idx = np.arange(n, dtype=np.int64)
+    x = idx % nx
+    y = idx // nx
+    rows, cols, vals = [], [], []
+    for dy in range(0, radius + 1):
+        for dx in range(-radius, radius + 1):
+            if dy == 0 and dx <= 0:
+                continue
+            if abs(dx) == radius and abs(dy) == radius:
+                continue
+            mask = (x + dx >= 0) & (x + dx < nx) & (y + dy < ny)
+            j = idx[mask]
+            i = j + dx + dy * nx
+            rows.append(i)
+            cols.append(j)
+            vals.append(-rng.random(j.size))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    dsum = np.ones(n)
+    np.add.at(dsum, rows, np.abs(vals))
+    np.add.at(dsum, cols, np.abs(vals))
+    rows = np.concatenate([idx, rows])
+    cols = np.concatenate([idx, cols])
+    vals = np.concatenate([dsum, vals])
+    Cp, Ci, Cx = _csc_from_coo(n, rows, cols, vals)
+    return n, Cp, Ci, Cx
+
+
+def random_spd_lower(n, nnz_per_col=4, seed=0, bandwidth=None):
+    """small random SPD test matrix: random lower pattern (optionally banded), values U(-1,1),
+    diagonal = 1 + sum|offdiag| over the row/column."""
+    rng = np.random.default_rng(seed)
+    cols = np.repeat(np.arange(n, dtype=np.int64), nnz_per_col)
+    if bandwidth is None:
+        rows = rng.integers(0, n, size=cols.size)
+    else:
+        rows = np.minimum(cols + rng.integers(1, bandwidth + 1, size=cols.size), n - 1)
+    lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+    keep = lo != hi
+    lo, hi = lo[keep], hi[keep]
+    key = np.unique(hi * n + lo)
+    hi, lo = key // n, key % n
+    vals = rng.uniform(-1, 1, size=hi.size)
+    dsum = np.ones(n)
+    np.add.at(dsum, hi, np.abs(vals))
+    np.add.at(dsum, lo, np.abs(vals))
+    idx = np.arange(n, dtype=np.int64)
+    rows = np.concatenate([idx, hi])
+    cc = np.concatenate([idx, lo])
+    vv = np.concatenate([dsum, vals])
+    Cp, Ci, Cx = _csc_from_coo(n, rows, cc, vv)
+    return n, Cp, Ci, Cx
+
+
+def arrow_spd_lower(n, width=1):
+    """arrow-head: dense last `width` rows + diagonal (a relaxed-amalgamation edge case)."""
+    idx = np.arange(n, dtype=np.int64)
+    rows, cols, vals = [idx], [idx], [np.full(n, float(n + 1))]
+    for w in range(width):
+        r = n - 1 - w
+        j = idx[idx < r]
+        rows.append(np.full(j.size, r, dtype=np.int64))
+        cols.append(j)
+        vals.append(np.full(j.size, -0.5 / (w + 1)))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    Cp, Ci, Cx = _csc_from_coo(n, rows, cols, vals)
+    return n, Cp, Ci, Cx
+
+
+def dense_from_lower(n, Cp, Ci, Cx):
+    """dense symmetric matrix from a stored triangle (small n only)."""
+    A = np.zeros((n, n))
+    for j in range(n):
+        for p in range(Cp[j], Cp[j + 1]):
+            A[Ci[p], j] = Cx[p]
+            A[j, Ci[p]] = Cx[p]
+    return A
+
+
+def write_matrix_market(path, n, Cp, Ci, Cx, symmetric=True):
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real %s\n" % ("symmetric" if symmetric else "general"))
+        f.write("%d %d %d\n" % (n, n, len(Ci)))
+        for j in range(n):
+            for p in range(Cp[j], Cp[j + 1]):
+                f.write("%d %d %.17g\n" % (Ci[p] + 1, j + 1, Cx[p]))
