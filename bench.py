@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- numeric-factorization throughput of the MI355X-native supernodal Cholesky.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload at N = 1 (BASELINE.json configs[1]): 3-D 7-point Laplacian 128^3, SPD, fp64, deterministic
+geometric nested dissection, devSlotSize = the reference's formula for one 288 GiB device.
+A "step" = one complete numeric factorization (assemble + every panel + every Schur update) with the
+matrix values, the symbolic structure and the task tables already resident in HBM; the factor stays
+in HBM.  value = F_struct * N / t  with  F_struct = sum_j ColCount_j^2  (SURVEY 8d).
+N > 1: one process per GPU, each factorizes its own matrix of the same shape (the reference's own
+multi-matrix mode, SparseFrame.c:3375); no data-path collective; "weak" scaling.
+
+The JSON line also carries
+  roofline     : the Schur-update kernel (k_gemm<1>: fp64 MFMA GEMM + fused mapped scatter), executed
+                 update flops / its summed launch time (HIP events on the plan's stream)
+  cpu_baseline : the CPU oracle (a port of the reference's CPU path on OpenBLAS) on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix; v_mfma_f64_16x16x4_f64 = 2048 flop / 64 cyc / SIMD
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=128, help="N of the N^3 Laplacian (128 = BASELINE config 2)")
+    ap.add_argument("--cpu-grid", type=int, default=72, help="N of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="BLAS threads of the CPU baseline (0 = min(cores,16))")
+    ap.add_argument("--check", action="store_true", help="download the factor and check the residual on the host")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ngpu = max(args.gpus, 1)
+    if world != ngpu and world > 1:
+        raise SystemExit(f"--gpus {ngpu} but WORLD_SIZE={world}")
+
+    sf = importlib.import_module("sparse-matrix-factorization-library_amd")
+    if sf.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the numeric path has no CPU fallback")
+
+    N = args.grid
+    t0 = time.time()
+    n, Cp, Ci, Cx = sf.gen.laplacian_lower(N, N, N)
+    perm = sf.grid_nd_perm(N, N, N, 3, 1)
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, sf.REFERENCE_SLOT_1GPU)
+    t_analyze = time.time() - t0
+    F_struct, F_exec = sym.flops_struct, sym.flops_exec
+
+    t0 = time.time()
+    plan = sf.CholPlan(sym, device=local_rank)
+    plan.set_values(sym.Lx)
+    t_plan = time.time() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.factorize(sync=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.factorize(sync=False)
+    plan.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = F_struct * ngpu / (elapsed / args.steps) / 1e9
+
+    out = {
+        "metric": "numeric-factorization GFLOP/s (supernodal Cholesky)",
+        "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
+                   "n": n, "nnz_lower": int(sym.nnz), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
+                   "F_struct": F_struct, "F_exec": F_exec,
+                   "parallelism": "1 matrix per GPU (independent)" if ngpu > 1 else "single GPU",
+                   "exec_GFLOPs": round(F_exec * ngpu / (elapsed / args.steps) / 1e9, 2),
+                   "host_analyze_s": round(t_analyze, 2), "plan_create_s": round(t_plan, 2)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        plan.set_profiling(True)
+        plan.factorize(sync=True)
+        plan.set_profiling(False)
+        upd_ms = plan.stat("last_update_ms")
+        achieved = plan.stat("flops_update") / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<1> (Schur update, fused scatter)",
+                           "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel_ms": round(upd_ms, 3), "panel_ms": round(plan.stat("last_panel_ms"), 3),
+                           "load_ms": round(plan.stat("last_load_ms"), 3),
+                           "flops_update": plan.stat("flops_update"),
+                           "launches": int(plan.stat("launches")), "levels": int(plan.stat("levels"))}
+
+    if args.check and rank == 0:
+        import oracle
+        Lsx = plan.get_factor()
+        res, _ = oracle.chol_residual(sym, Lsx)
+        out["config"]["residual"] = res
+        del Lsx
+
+    if rank == 0 and ngpu == 1 and args.cpu_grid > 0:
+        import oracle
+        threads = args.cpu_threads or min(os.cpu_count() or 1, 16)   # reference: min(omp_max, 16), SparseFrame.c:3357
+        binfo = oracle.blas_init("auto", threads=threads)
+        M = args.cpu_grid
+        n2, Cp2, Ci2, Cx2 = sf.gen.laplacian_lower(M, M, M)
+        sym2 = sf.analyze(n2, Cp2, Ci2, Cx2, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU)
+        oracle.chol_factorize(sym2)   # warm-up: first-touch page faults dominated the reference probe
+        _, info, st = oracle.chol_factorize(sym2)
+        out["cpu_baseline"] = {"value": round(sym2.flops_struct / st["seconds"] / 1e9, 2), "unit": "GFLOP/s",
+                               "cores": int(binfo["threads"]), "kind": "port",
+                               "sample": f"3D 7-point Laplacian {M}^3 (same generator and ordering), full numeric "
+                                         f"factorization, F_struct {sym2.flops_struct:.3e}, {st['seconds']:.2f} s, "
+                                         f"1 tree worker x {binfo['threads']} BLAS threads, "
+                                         f"{os.path.basename(binfo['name'])}",
+                               "info": int(info)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -231,6 +231,9 @@ int sf_chol_plan_destroy(sf_chol_plan *plan);
 int sf_device_count(void);
 /* version string */
 const char *sf_version(void);
+/* layout probe for FFI authors: "sizeof_common", "sizeof_matrix", "offsetof_Lsx", "offsetof_workspace",
+ * "offsetof_residual", "offsetof_devSlotSize" as this library was compiled; -1 for an unknown name */
+long sf_abi_layout(const char *name);
 
 #ifdef __cplusplus
 }

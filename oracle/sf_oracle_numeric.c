@@ -1,0 +1,369 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+ *
+ * CPU restatement ("oracle") of the reference's supernodal numeric Cholesky path, real fp64:
+ *
+ *   sfo_assemble_panel        <- SparseFrame_loadA              Cholesky/Source/SparseFrame.c:1998-2028
+ *   sfo_apply_descendant      <- SparseFrame_cpuApply           :2030-2102
+ *   sfo_factor_supernode      <- SparseFrame_cpuApplyFactorize  :2104-2148
+ *   sfo_chol_factorize        <- SparseFrame_factorize_supernodal, CPU worker  :2150-2343, :2955-2987
+ *                                (one worker: the reference default MAX_NUM_CPU = 0 gives numCPU = 1
+ *                                 when no GPU is present, :45-53)
+ *   sfo_chol_solve            <- SparseFrame_solve_supernodal   :3036-3139
+ *   sfo_chol_residual         <- SparseFrame_validate           :3141-3266
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's library;
+ * the product (libsparseframe_hip.so) never does.
+ *
+ * PARITY STATUS: the reference cannot be built in this image without stand-in headers for
+ * CUDA/cuBLAS/cuSOLVER/MAGMA/METIS/SuiteSparse (treated as unbuildable), and it ships no tests or golden
+ * vectors.  This restatement is pinned by (a) the integer counts of reference runs recorded in
+ * SURVEY.md Appendix C (through the symbolic layer it is driven by), and (b) the uniqueness of the
+ * Cholesky factor: tests compare it with dense LAPACK factorizations.  Bitwise reference outputs
+ * for Lsx do not exist: "parity unpinned" for the floating-point values in that strict sense.
+ *
+ * BLAS: the reference links an unpinned -lopenblas through Fortran symbols taking Long* dimensions
+ * (Include/extern.h:6-13).  Here the four routines are resolved at run time from the OpenBLAS that
+ * scipy bundles (LP64 "scipy_" symbols), or from the ILP64 build numpy bundles, or fall back to the
+ * plain-C loops at the bottom of this file.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef int64_t Long;
+
+/* ------------------------------------------------------------------------------------------------
+ * BLAS back end
+ * ------------------------------------------------------------------------------------------------ */
+typedef void (*syrk32_t)(const char*, const char*, const int*, const int*, const double*, const double*, const int*, const double*, double*, const int*);
+typedef void (*gemm32_t)(const char*, const char*, const int*, const int*, const int*, const double*, const double*, const int*, const double*, const int*, const double*, double*, const int*);
+typedef void (*potrf32_t)(const char*, const int*, double*, const int*, int*);
+typedef void (*trsm32_t)(const char*, const char*, const char*, const char*, const int*, const int*, const double*, const double*, const int*, double*, const int*);
+typedef void (*syrk64_t)(const char*, const char*, const Long*, const Long*, const double*, const double*, const Long*, const double*, double*, const Long*);
+typedef void (*gemm64_t)(const char*, const char*, const Long*, const Long*, const Long*, const double*, const double*, const Long*, const double*, const Long*, const double*, double*, const Long*);
+typedef void (*potrf64_t)(const char*, const Long*, double*, const Long*, Long*);
+typedef void (*trsm64_t)(const char*, const char*, const char*, const char*, const Long*, const Long*, const double*, const double*, const Long*, double*, const Long*);
+
+static struct {
+    int kind; /* 0 = built-in C loops, 32 = LP64 library, 64 = ILP64 library */
+    void* handle;
+    syrk32_t syrk32; gemm32_t gemm32; potrf32_t potrf32; trsm32_t trsm32;
+    syrk64_t syrk64; gemm64_t gemm64; potrf64_t potrf64; trsm64_t trsm64;
+    void (*set_threads)(int);
+    int (*get_threads)(void);
+    char name[512];
+} B = {0};
+
+static void* sym2(void* h, const char* a, const char* b) {
+    void* p = dlsym(h, a);
+    return p ? p : dlsym(h, b);
+}
+
+/* path == NULL or "builtin": plain C loops.  Returns the integer width bound (0, 32, 64) or -1. */
+int sfo_blas_init(const char* path) {
+    if (B.handle) { dlclose(B.handle); }
+    memset(&B, 0, sizeof(B));
+    strcpy(B.name, "builtin-c-loops");
+    if (!path || strcmp(path, "builtin") == 0) return 0;
+    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return -1;
+    void* s = sym2(h, "scipy_dsyrk_", "dsyrk_");
+    if (s) {
+        B.syrk32 = (syrk32_t)s;
+        B.gemm32 = (gemm32_t)sym2(h, "scipy_dgemm_", "dgemm_");
+        B.potrf32 = (potrf32_t)sym2(h, "scipy_dpotrf_", "dpotrf_");
+        B.trsm32 = (trsm32_t)sym2(h, "scipy_dtrsm_", "dtrsm_");
+        if (!B.gemm32 || !B.potrf32 || !B.trsm32) { dlclose(h); return -1; }
+        B.kind = 32;
+    } else {
+        s = sym2(h, "scipy_dsyrk_64_", "dsyrk_64_");
+        if (!s) { dlclose(h); return -1; }
+        B.syrk64 = (syrk64_t)s;
+        B.gemm64 = (gemm64_t)sym2(h, "scipy_dgemm_64_", "dgemm_64_");
+        B.potrf64 = (potrf64_t)sym2(h, "scipy_dpotrf_64_", "dpotrf_64_");
+        B.trsm64 = (trsm64_t)sym2(h, "scipy_dtrsm_64_", "dtrsm_64_");
+        if (!B.gemm64 || !B.potrf64 || !B.trsm64) { dlclose(h); return -1; }
+        B.kind = 64;
+    }
+    B.set_threads = (void (*)(int))sym2(h, B.kind == 32 ? "scipy_openblas_set_num_threads" : "scipy_openblas_set_num_threads64_", "openblas_set_num_threads");
+    B.get_threads = (int (*)(void))sym2(h, B.kind == 32 ? "scipy_openblas_get_num_threads" : "scipy_openblas_get_num_threads64_", "openblas_get_num_threads");
+    B.handle = h;
+    snprintf(B.name, sizeof(B.name), "%s", path);
+    return B.kind;
+}
+
+const char* sfo_blas_name(void) { return B.name[0] ? B.name : "builtin-c-loops"; }
+int sfo_blas_kind(void) { return B.kind; }
+void sfo_blas_set_threads(int n) { if (B.set_threads) B.set_threads(n); }
+int sfo_blas_get_threads(void) { return B.get_threads ? B.get_threads() : 1; }
+
+/* built-in loops, column-major */
+static void c_syrk_ln(Long n, Long k, const double* A, Long lda, double* C, Long ldc) {
+    /* C(lower) = A A^T, A is n x k */
+    for (Long j = 0; j < n; j++) {
+        for (Long i = j; i < n; i++) C[i + j * ldc] = 0.0;
+        for (Long p = 0; p < k; p++) {
+            const double ajp = A[j + p * lda];
+            for (Long i = j; i < n; i++) C[i + j * ldc] += A[i + p * lda] * ajp;
+        }
+    }
+}
+static void c_gemm_nt(Long m, Long n, Long k, const double* A, Long lda, const double* Bm, Long ldb, double* C, Long ldc) {
+    /* C = A B^T, A is m x k, B is n x k */
+    for (Long j = 0; j < n; j++) {
+        for (Long i = 0; i < m; i++) C[i + j * ldc] = 0.0;
+        for (Long p = 0; p < k; p++) {
+            const double bjp = Bm[j + p * ldb];
+            for (Long i = 0; i < m; i++) C[i + j * ldc] += A[i + p * lda] * bjp;
+        }
+    }
+}
+static int c_potrf_l(Long n, double* A, Long lda) {
+    for (Long j = 0; j < n; j++) {
+        double d = A[j + j * lda];
+        for (Long p = 0; p < j; p++) d -= A[j + p * lda] * A[j + p * lda];
+        if (!(d > 0.0)) return (int)(j + 1);
+        d = sqrt(d);
+        A[j + j * lda] = d;
+        for (Long i = j + 1; i < n; i++) {
+            double v = A[i + j * lda];
+            for (Long p = 0; p < j; p++) v -= A[i + p * lda] * A[j + p * lda];
+            A[i + j * lda] = v / d;
+        }
+    }
+    return 0;
+}
+static void c_trsm_rltn(Long m, Long n, const double* A, Long lda, double* X, Long ldx) {
+    /* X <- X * A^{-T}, A lower n x n non-unit, X is m x n */
+    for (Long j = 0; j < n; j++) {
+        for (Long p = 0; p < j; p++) {
+            const double ajp = A[j + p * lda];
+            for (Long i = 0; i < m; i++) X[i + j * ldx] -= X[i + p * ldx] * ajp;
+        }
+        const double d = A[j + j * lda];
+        for (Long i = 0; i < m; i++) X[i + j * ldx] /= d;
+    }
+}
+
+static void blas_syrk(Long n, Long k, const double* A, Long lda, double* C, Long ldc) {
+    const double one = 1.0, zero = 0.0;
+    if (n <= 0) return;
+    if (B.kind == 32) { int n_ = (int)n, k_ = (int)k, a_ = (int)lda, c_ = (int)ldc; B.syrk32("L", "N", &n_, &k_, &one, A, &a_, &zero, C, &c_); }
+    else if (B.kind == 64) B.syrk64("L", "N", &n, &k, &one, A, &lda, &zero, C, &ldc);
+    else c_syrk_ln(n, k, A, lda, C, ldc);
+}
+static void blas_gemm_nt(Long m, Long n, Long k, const double* A, Long lda, const double* Bm, Long ldb, double* C, Long ldc) {
+    const double one = 1.0, zero = 0.0;
+    if (m <= 0 || n <= 0) return;
+    if (B.kind == 32) { int m_ = (int)m, n_ = (int)n, k_ = (int)k, a_ = (int)lda, b_ = (int)ldb, c_ = (int)ldc; B.gemm32("N", "C", &m_, &n_, &k_, &one, A, &a_, Bm, &b_, &zero, C, &c_); }
+    else if (B.kind == 64) B.gemm64("N", "C", &m, &n, &k, &one, A, &lda, Bm, &ldb, &zero, C, &ldc);
+    else c_gemm_nt(m, n, k, A, lda, Bm, ldb, C, ldc);
+}
+static int blas_potrf(Long n, double* A, Long lda) {
+    if (n <= 0) return 0;
+    if (B.kind == 32) { int n_ = (int)n, a_ = (int)lda, info = 0; B.potrf32("L", &n_, A, &a_, &info); return info; }
+    if (B.kind == 64) { Long info = 0; B.potrf64("L", &n, A, &lda, &info); return (int)info; }
+    return c_potrf_l(n, A, lda);
+}
+static void blas_trsm(Long m, Long n, const double* A, Long lda, double* X, Long ldx) {
+    const double one = 1.0;
+    if (m <= 0 || n <= 0) return;
+    if (B.kind == 32) { int m_ = (int)m, n_ = (int)n, a_ = (int)lda, x_ = (int)ldx; B.trsm32("R", "L", "C", "N", &m_, &n_, &one, A, &a_, X, &x_); }
+    else if (B.kind == 64) B.trsm64("R", "L", "C", "N", &m, &n, &one, A, &lda, X, &ldx);
+    else c_trsm_rltn(m, n, A, lda, X, ldx);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * numeric path
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    Long n, nsuper;
+    const Long *Super, *SuperMap, *Lsip, *Lsi, *Lsxp, *Lp, *Li;
+    const double* Lx;
+    double* Lsx;
+    Long *Head, *Next, *Lpos;   /* descendant lists (reference :2221-2224) */
+    Long *Map, *RelMap;         /* :2310-2311 */
+    double* C;                  /* update scratch, csize doubles (:2313) */
+    /* instrumentation */
+    double flops_syrk, flops_gemm, flops_potrf, flops_trsm, scatter_elems;
+    int info;
+} sfo_ctx;
+
+/* reference :1998-2028 -- zero the panel, scatter the columns of lower(PAP^T) through Map */
+static void sfo_assemble_panel(sfo_ctx* c, Long s, double* A, Long nscol, Long lda) {
+    memset(A, 0, (size_t)(nscol * lda) * sizeof(double));
+    for (Long j = c->Super[s]; j < c->Super[s + 1]; j++) {
+        double* col = A + (j - c->Super[s]) * lda;
+        for (Long p = c->Lp[j]; p < c->Lp[j + 1]; p++) col[c->Map[c->Li[p]]] = c->Lx[p];
+    }
+}
+
+/* reference :2030-2102 -- one descendant d updates supernode s */
+static void sfo_apply_descendant(sfo_ctx* c, Long s, Long nsrow, double* A, Long d) {
+    const Long ndcol = c->Super[d + 1] - c->Super[d];
+    const Long ndrow = c->Lsip[d + 1] - c->Lsip[d];
+    const Long* drows = c->Lsi + c->Lsip[d];
+    const Long lpos = c->Lpos[d];
+    Long lpos_next = lpos;
+    while (lpos_next < ndrow && drows[lpos_next] < c->Super[s + 1]) lpos_next++;   /* :2047 */
+
+    const Long dn = lpos_next - lpos, dm = ndrow - lpos_next, dk = ndcol;
+    const Long dlda = ndrow, dldc = ndrow - lpos;
+    const double* Ld = c->Lsx + c->Lsxp[d];
+
+    for (Long di = 0; di < ndrow - lpos; di++) c->RelMap[di] = c->Map[drows[lpos + di]];   /* :2055-2058 */
+
+    blas_syrk(dn, dk, Ld + lpos, dlda, c->C, dldc);                                     /* :2061 */
+    if (dm > 0) blas_gemm_nt(dm, dn, dk, Ld + lpos_next, dlda, Ld + lpos, dlda, c->C + dn, dldc);  /* :2068 */
+    c->flops_syrk += (double)dn * (dn + 1) * dk;
+    c->flops_gemm += 2.0 * dm * dn * dk;
+
+    for (Long cj = 0; cj < dn; cj++) {                                                   /* :2073-2086 */
+        double* acol = A + c->RelMap[cj] * nsrow;
+        const double* ccol = c->C + cj * dldc;
+        for (Long ci = cj; ci < dn + dm; ci++) acol[c->RelMap[ci]] -= ccol[ci];
+    }
+    c->scatter_elems += (double)dn * (dn + 1) / 2 + (double)dm * dn;
+
+    if (lpos_next < ndrow) {                                                             /* :2088-2098 */
+        const Long anc = c->SuperMap[drows[lpos_next]];
+        c->Next[d] = c->Head[anc];
+        c->Head[anc] = d;
+    }
+    c->Lpos[d] = lpos_next;
+}
+
+/* reference :2104-2148 */
+static void sfo_factor_supernode(sfo_ctx* c, Long s) {
+    const Long nscol = c->Super[s + 1] - c->Super[s];
+    const Long nsrow = c->Lsip[s + 1] - c->Lsip[s];
+    const Long* rows = c->Lsi + c->Lsip[s];
+    for (Long si = 0; si < nsrow; si++) c->Map[rows[si]] = si;                           /* :2113-2114 */
+    double* A = c->Lsx + c->Lsxp[s];
+    sfo_assemble_panel(c, s, A, nscol, nsrow);
+    while (c->Head[s] >= 0) {                                                            /* :2123-2132 */
+        const Long d = c->Head[s];
+        c->Head[s] = c->Next[d];
+        sfo_apply_descendant(c, s, nsrow, A, d);
+    }
+    const int info = blas_potrf(nscol, A, nsrow);                                        /* :2135 */
+    if (info && !c->info) c->info = info;
+    if (nscol < nsrow) blas_trsm(nsrow - nscol, nscol, A, nsrow, A + nscol, nsrow);      /* :2142 */
+    c->flops_potrf += (double)nscol * nscol * nscol / 3.0;
+    c->flops_trsm += (double)(nsrow - nscol) * nscol * nscol;
+}
+
+/* reference :2150-2343 + :2955-2987, single worker.  LeafQueue_in holds the nsleaf initial leaves
+ * (in stage order, as SparseFrame_analyze_supernodal leaves them); parents are appended as their
+ * last child finishes.  stats (may be NULL): [syrk, gemm, potrf, trsm flops, scatter elems, seconds]. */
+int sfo_chol_factorize(Long n, Long nsuper, const Long* Super, const Long* SuperMap,
+                       const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                       const Long* Lp, const Long* Li, const double* Lx,
+                       const Long* LeafQueue_in, Long nsleaf, Long csize,
+                       double* Lsx, double* stats) {
+    sfo_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.n = n; c.nsuper = nsuper;
+    c.Super = Super; c.SuperMap = SuperMap; c.Lsip = Lsip; c.Lsi = Lsi; c.Lsxp = Lsxp;
+    c.Lp = Lp; c.Li = Li; c.Lx = Lx; c.Lsx = Lsx;
+    const size_t ns1 = (size_t)(nsuper > 0 ? nsuper : 1), n1 = (size_t)(n > 0 ? n : 1);
+    c.Head = malloc(ns1 * sizeof(Long));
+    c.Next = malloc(ns1 * sizeof(Long));
+    c.Lpos = malloc(ns1 * sizeof(Long));
+    Long* Nschild = calloc(ns1, sizeof(Long));
+    Long* Queue = malloc(ns1 * sizeof(Long));
+    c.Map = malloc(n1 * sizeof(Long));
+    c.RelMap = malloc(n1 * sizeof(Long));
+    c.C = malloc((size_t)(csize > 0 ? csize : 1) * sizeof(double));
+    if (!c.Head || !c.Next || !c.Lpos || !Nschild || !Queue || !c.Map || !c.RelMap || !c.C) return -1;
+
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+
+    for (Long s = 0; s < nsuper; s++) { c.Head[s] = -1; c.Next[s] = -1; c.Lpos[s] = 0; }   /* :2230-2262 */
+    for (Long s = 0; s < nsuper; s++) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        if (nscol < nsrow) Nschild[SuperMap[Lsi[Lsip[s] + nscol]]]++;
+    }
+    Long head = 0, tail = nsleaf;
+    for (Long k = 0; k < nsleaf; k++) Queue[k] = LeafQueue_in[k];
+
+    while (head < tail) {                                                                /* :2331 */
+        const Long s = Queue[head++];
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        sfo_factor_supernode(&c, s);                                                     /* :2957 */
+        c.Lpos[s] = nscol;                                                               /* :2960 */
+        if (nscol < nsrow) {                                                             /* :2962-2978 */
+            const Long sparent = SuperMap[Lsi[Lsip[s] + nscol]];
+            c.Next[s] = c.Head[sparent];
+            c.Head[sparent] = s;
+            if (--Nschild[sparent] <= 0) Queue[tail++] = sparent;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (stats) {
+        stats[0] = c.flops_syrk; stats[1] = c.flops_gemm; stats[2] = c.flops_potrf; stats[3] = c.flops_trsm;
+        stats[4] = c.scatter_elems;
+        stats[5] = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    }
+    const int done = (head == nsuper);
+    free(c.Head); free(c.Next); free(c.Lpos); free(Nschild); free(Queue); free(c.Map); free(c.RelMap); free(c.C);
+    if (!done) return -2;     /* queue starved: inconsistent symbolic input */
+    return c.info;            /* 0, or LAPACK's info of the first failing diagonal block */
+}
+
+/* reference :3036-3139 -- x starts as b (permuted space) */
+void sfo_chol_solve(Long nsuper, const Long* Super, const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                    const double* Lsx, Long n, const double* b, double* x) {
+    memcpy(x, b, (size_t)n * sizeof(double));
+    for (Long s = 0; s < nsuper; s++) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        for (Long sj = 0; sj < nscol; sj++) {
+            const Long j = Lsi[Lsip[s] + sj];
+            x[j] /= Lsx[Lsxp[s] + sj * nsrow + sj];
+            for (Long si = sj + 1; si < nsrow; si++) x[Lsi[Lsip[s] + si]] -= Lsx[Lsxp[s] + sj * nsrow + si] * x[j];
+        }
+    }
+    for (Long s = nsuper - 1; s >= 0; s--) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        for (Long sj = nscol - 1; sj >= 0; sj--) {
+            const Long j = Lsi[Lsip[s] + sj];
+            for (Long si = sj + 1; si < nsrow; si++) x[j] -= Lsx[Lsxp[s] + sj * nsrow + si] * x[Lsi[Lsip[s] + si]];
+            x[j] /= Lsx[Lsxp[s] + sj * nsrow + sj];
+        }
+    }
+}
+
+/* reference :3182-3263 -- b_i = 1 + i/n; returns |Ax-b|_inf / (|A|_1 |x|_inf + |b|_inf); x is written */
+double sfo_chol_residual(Long n, const Long* Lp, const Long* Li, const double* Lx,
+                         Long nsuper, const Long* Super, const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                         const double* Lsx, double* x) {
+    double* b = malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    double* r = malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    double* w = calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    for (Long i = 0; i < n; i++) b[i] = 1 + i / (double)n;
+    sfo_chol_solve(nsuper, Super, Lsip, Lsi, Lsxp, Lsx, n, b, x);
+    for (Long i = 0; i < n; i++) r[i] = -b[i];
+    for (Long j = 0; j < n; j++)
+        for (Long p = Lp[j]; p < Lp[j + 1]; p++) {
+            const Long i = Li[p];
+            r[i] += Lx[p] * x[j];
+            w[j] += fabs(Lx[p]);
+            if (i != j) { r[j] += Lx[p] * x[i]; w[i] += fabs(Lx[p]); }
+        }
+    double anorm = 0, bnorm = 0, xnorm = 0, rnorm = 0;
+    for (Long i = 0; i < n; i++) {
+        if (w[i] > anorm) anorm = w[i];
+        if (fabs(b[i]) > bnorm) bnorm = fabs(b[i]);
+        if (fabs(x[i]) > xnorm) xnorm = fabs(x[i]);
+        if (fabs(r[i]) > rnorm) rnorm = fabs(r[i]);
+    }
+    free(b); free(r); free(w);
+    return rnorm / (anorm * xnorm + bnorm);
+}

@@ -4,6 +4,7 @@
 #include <sparseframe_hip.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -45,6 +46,18 @@ void free_and_null(void** p) {
 extern "C" {
 
 const char* sf_version(void) { return "sparseframe-hip 0.1 (gfx950)"; }
+
+long sf_abi_layout(const char* name) {
+    if (!name) return -1;
+    const std::string k(name);
+    if (k == "sizeof_common") return (long)sizeof(struct common_info_struct);
+    if (k == "sizeof_matrix") return (long)sizeof(struct matrix_info_struct);
+    if (k == "offsetof_Lsx") return (long)offsetof(struct matrix_info_struct, Lsx);
+    if (k == "offsetof_workspace") return (long)offsetof(struct matrix_info_struct, workspace);
+    if (k == "offsetof_residual") return (long)offsetof(struct matrix_info_struct, residual);
+    if (k == "offsetof_devSlotSize") return (long)offsetof(struct common_info_struct, devSlotSize);
+    return -1;
+}
 
 // ------------------------------------------------------------------------------------------
 // flat symbolic ABI

@@ -42,9 +42,9 @@ def laplacian_lower(nx, ny=1, nz=1, diag=None):
 
 
 def stencil_spd_lower(nx, ny, radius=2, seed=12345):
-    """BASELINE config 3 stand-in: 2-D grid, all neighbours within Chebyshev... no: within the
-    radius-2 *diamond plus box corners* 21-point stencil (|dx|,|dy| <= 2 without the 4 far corners),
-    off-diagonals U(-1,0), diagonal 1 + sum|offdiag| (strictly diagonally dominant => SPD)."""
+    """BASELINE config 3 stand-in: 2-D grid, 21-point stencil (|dx|,|dy| <= radius without
+    the 4 far corners), off-diagonals U(-1,0), diagonal 1 + sum|offdiag| (strictly diagonally
+    dominant => SPD)."""
     n = nx * ny
     rng = np.random.default_rng(seed)
     idx = np.arange(n, dtype=np.int64)
@@ -127,7 +127,7 @@ def dense_from_lower(n, Cp, Ci, Cx):
 
 def write_matrix_market(path, n, Cp, Ci, Cx, symmetric=True):
     with open(path, "w") as f:
-        f.write("%%MatrixMarket matrix coordinate real %s\n" % ("symmetric" if symmetric else "general"))
+        f.write("%%MatrixMarket matrix coordinate real " + ("symmetric" if symmetric else "general") + "\n")
         f.write("%d %d %d\n" % (n, n, len(Ci)))
         for j in range(n):
             for p in range(Cp[j], Cp[j + 1]):

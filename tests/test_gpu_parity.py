@@ -1,0 +1,158 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs (fp64 tolerance of SURVEY 8(c): max |Lsx - ref| / max |ref| <= 1e-12 on the entries the
+reference defines, residual <= 1e-13), against the committed golden fixtures, and -- at sizes the
+dense check cannot reach -- through size-independent properties."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import sf, gen, nd_perm_py, small_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL_FACTOR = 1e-12
+TOL_RESIDUAL = 1e-13
+
+
+def gpu_factor(sym):
+    plan = sf.CholPlan(sym, device=0)
+    plan.set_values(sym.Lx)
+    plan.factorize()
+    Lsx = plan.get_factor()
+    return plan, Lsx
+
+
+@pytest.mark.parametrize("case", small_cases(), ids=lambda c: c[0])
+def test_factor_matches_oracle(oracle, case):
+    name, n, Cp, Ci, Cx, perm, slot = case
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    plan, Lsx = gpu_factor(sym)
+    ref, info, _ = oracle.chol_factorize(sym)
+    assert info == 0
+    mask = oracle.lower_mask(sym)
+    assert rel_err(Lsx, ref, mask) <= TOL_FACTOR
+    res, _ = oracle.chol_residual(sym, Lsx)
+    assert res <= TOL_RESIDUAL
+    plan.close()
+
+
+def test_golden_fixtures():
+    """fixtures made by tests/golden/make_golden.py (oracle with its built-in C loops, checked there
+    against dense LAPACK); no oracle code runs here"""
+    with open(os.path.join(HERE, "golden", "chol_small.json")) as f:
+        G = json.load(f)
+    for name, g in G.items():
+        sym = sf.analyze(g["n"], g["Cp"], g["Ci"], g["Cx"], g["perm"], g["devSlotSize"])
+        for k in ("Super", "Lsip", "Lsxp", "Lsi", "Perm", "LeafQueue"):
+            assert np.array_equal(getattr(sym, k), np.asarray(g[k], dtype=np.int64)), (name, k)
+        plan, Lsx = gpu_factor(sym)
+        want = np.asarray(g["Lsx"])
+        mask = np.asarray(g["mask"], dtype=bool)
+        assert rel_err(Lsx, want, mask) <= TOL_FACTOR, name
+        plan.close()
+
+
+def test_struct_entry_points_end_to_end(oracle, tmp_path):
+    """the reference driver's call order (SparseFrame.c:3396-3423) through the struct ABI:
+    BASELINE config 1 = 2-D 5-pt Laplacian 100x100 from a MatrixMarket file"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(100, 100)
+    path = tmp_path / "lap100.mtx"
+    gen.write_matrix_market(path, n, Cp, Ci, Cx)
+    common = sf.CommonInfo()
+    assert common.c.numGPU >= 1 and common.c.devSlotSize > (1 << 30)
+    common.c.devSlotSize = 1 << 30
+    mi = sf.MatrixInfo()
+    mi.read(path)
+    mi.analyze(common)
+    assert (mi.c.nsuper, mi.c.nstage) == (155, 1)
+    mi.factorize(common)
+    res = mi.validate()
+    assert res <= TOL_RESIDUAL
+    sym = sf.analyze(n, Cp, Ci, Cx, None, 1 << 30)
+    ref, info, _ = oracle.chol_factorize(sym)
+    Lsx = mi.array("Lsx", sym.xsize).copy()
+    assert rel_err(Lsx, ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+    assert mi.c.factorizeTime > 0
+    mi.cleanup()
+    common.close()
+
+
+def test_not_positive_definite_is_reported():
+    n, Cp, Ci, Cx = gen.laplacian_lower(6, 6)
+    Cx = Cx.copy()
+    Cx[Cp[20]] = -1.0
+    sym = sf.analyze(n, Cp, Ci, Cx, None, 1 << 30)
+    plan = sf.CholPlan(sym)
+    plan.set_values(sym.Lx)
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_NOT_POSDEF"):
+        plan.factorize()
+    plan.close()
+
+
+def test_refactorize_same_pattern_new_values(oracle):
+    """a plan is reusable: new values, same structure; and repeated runs agree to rounding"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(10, 10, 10)
+    sym = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(10, 10, 10), 1 << 30)
+    plan = sf.CholPlan(sym)
+    mask = oracle.lower_mask(sym)
+    for scale in (1.0, 3.5):
+        plan.set_values(sym.Lx * scale)
+        plan.factorize()
+        a = plan.get_factor()
+        plan.factorize()
+        b = plan.get_factor()
+        assert rel_err(a, b, mask) <= 1e-14
+        ref, info, _ = oracle.chol_factorize(dict(
+            n=n, nsuper=sym.nsuper, Super=sym.Super, SuperMap=sym.SuperMap, Lsip=sym.Lsip, Lsi=sym.Lsi,
+            Lsxp=sym.Lsxp, Lp=sym.Lp, Li=sym.Li, Lx=sym.Lx * scale, LeafQueue=sym.LeafQueue,
+            nsleaf=sym.nsleaf, csize=sym.csize, xsize=sym.xsize))
+        assert rel_err(a, ref, mask) <= TOL_FACTOR
+    plan.close()
+
+
+@pytest.mark.parametrize("N", [24, 40])
+def test_medium_3d_against_oracle(oracle, N):
+    """sizes with supernodes of several hundred to ~2500 columns: multi-step blocked panels, trailing
+    updates, multi-tile Schur updates"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), sf.REFERENCE_SLOT_1GPU)
+    plan, Lsx = gpu_factor(sym)
+    ref, info, _ = oracle.chol_factorize(sym)
+    assert info == 0
+    assert rel_err(Lsx, ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+    res, _ = oracle.chol_residual(sym, Lsx)
+    assert res <= TOL_RESIDUAL
+    assert abs(plan.stat("flops_exec") - sym.flops_exec) <= 1e-9 * sym.flops_exec
+    plan.close()
+
+
+def test_config3_like_2d_wide_stencil(oracle):
+    """BASELINE config 3's generator at reduced size (200x200 grid, 21-point stencil, 2-line separators)"""
+    n, Cp, Ci, Cx = gen.stencil_spd_lower(200, 200)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(200, 200, 1, 3, 2), sf.REFERENCE_SLOT_1GPU)
+    plan, Lsx = gpu_factor(sym)
+    ref, info, _ = oracle.chol_factorize(sym)
+    assert info == 0
+    assert rel_err(Lsx, ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+    res, _ = oracle.chol_residual(sym, Lsx)
+    assert res <= TOL_RESIDUAL
+    plan.close()
+
+
+def test_large_properties_64cubed(oracle):
+    """64^3 (n = 262,144): too big for a dense check; properties instead --
+    residual of the reference's validate(), and (L L^T)_{ij} = A_{ij} on sampled rows via the solve"""
+    N = 64
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), sf.REFERENCE_SLOT_1GPU)
+    plan, Lsx = gpu_factor(sym)
+    res, x = oracle.chol_residual(sym, Lsx)
+    assert res <= TOL_RESIDUAL
+    # linearity of the solve: (LL^T)^{-1}(2b) = 2 (LL^T)^{-1} b to rounding
+    b = 1 + np.arange(n) / n
+    x2 = oracle.chol_solve(sym, Lsx, 2 * b)
+    assert np.allclose(x2, 2 * x, rtol=1e-13, atol=0)
+    plan.close()

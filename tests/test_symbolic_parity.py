@@ -1,0 +1,89 @@
+"""Product host analysis (C++, libsparseframe_hip.so) against the oracle's Python restatement of the
+reference's SparseFrame_analyze: every integer output bit-exact for the same Perm and devSlotSize."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import sf, gen, nd_perm_py, small_cases, INT_ARRAYS, INT_SCALARS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RECORDED = json.load(open(os.path.join(HERE, "golden", "reference_recorded.json")))
+
+
+def assert_same(P, O):
+    for k in INT_SCALARS:
+        assert getattr(P, k) == O[k], k
+    for k in INT_ARRAYS:
+        a, b = np.asarray(getattr(P, k)), np.asarray(O[k], dtype=np.int64)
+        assert a.shape == b.shape, k
+        assert np.array_equal(a, b), k
+    assert np.array_equal(P.Lx, np.asarray(O["Lx"]))
+    assert np.array_equal(P.LTx, np.asarray(O["LTx"]))
+
+
+@pytest.mark.parametrize("case", small_cases(), ids=lambda c: c[0])
+def test_bit_exact_small(oracle, case):
+    name, n, Cp, Ci, Cx, perm, slot = case
+    P = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    O = oracle.symbolic.analyze(n, Cp, Ci, Cx, perm, slot)
+    assert_same(P, O)
+
+
+@pytest.mark.parametrize("slot", [1 << 30, 200_000, 20_000, 3_000])
+def test_bit_exact_slot_caps_and_stages(oracle, slot):
+    """small slots exercise the devSlotSize caps (C:1482-1494, C:1556-1574) and multi-stage packing"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(12, 12, 12)
+    perm = nd_perm_py(12, 12, 12)
+    P = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    O = oracle.symbolic.analyze(n, Cp, Ci, Cx, perm, slot)
+    assert_same(P, O)
+    if slot <= 20_000:
+        assert P.nstage > 1
+
+
+def test_config1_plumbing_counts(oracle):
+    """BASELINE config 1 (2-D 5-pt Laplacian 100x100): the counts a real reference run printed"""
+    rec = RECORDED["lap2d_100x100_identity_1GiB"]
+    n, Cp, Ci, Cx = gen.laplacian_lower(100, 100)
+    P = sf.analyze(n, Cp, Ci, Cx, None, 1 << 30)
+    assert (P.nfsuper, P.nsuper, P.nstage) == (rec["nfsuper"], rec["nsuper"], rec["nstage"])
+    O = oracle.symbolic.analyze(n, Cp, Ci, Cx, None, 1 << 30)
+    assert_same(P, O)
+
+
+def test_grid_nd_matches_python_restatement():
+    for dims in ((8, 8, 1), (30, 17, 1), (4, 4, 4), (12, 12, 12), (9, 5, 7), (1, 1, 1), (2, 2, 2)):
+        assert np.array_equal(sf.grid_nd_perm(*dims), nd_perm_py(*dims)), dims
+
+
+def test_recorded_reference_runs_3d(oracle):
+    """32^3 and 48^3: supernode counts and executed flops of the reference runs in SURVEY Appendix C,
+    through the product analysis + the oracle's instrumented numeric path"""
+    oracle.blas_init("auto", threads=4)
+    for N, key in ((32, "lap3d_32_geomND_8GiB"), (48, "lap3d_48_geomND_8GiB")):
+        rec = RECORDED[key]
+        n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+        P = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 8 << 30)
+        assert (P.nfsuper, P.nsuper) == (rec["nfsuper"], rec["nsuper"])
+        assert abs(P.flops_exec - rec["flops_exec"]) <= 0.005 * rec["flops_exec"]
+        Lsx, info, st = oracle.chol_factorize(P)
+        assert info == 0
+        tot = st["flops_syrk"] + st["flops_gemm"] + st["flops_potrf"] + st["flops_trsm"]
+        assert abs(tot - P.flops_exec) <= 1e-9 * tot
+        if "flops_syrk" in rec:
+            for k in ("flops_syrk", "flops_gemm", "flops_potrf", "flops_trsm", "scatter_elems"):
+                assert abs(st[k] - rec[k]) <= 0.006 * rec[k], (k, st[k], rec[k])
+        res, _ = oracle.chol_residual(P, Lsx)
+        assert res <= 1e-13
+
+
+def test_bad_inputs_are_rejected():
+    n, Cp, Ci, Cx = gen.laplacian_lower(4, 4)
+    with pytest.raises(sf.SparseFrameError):
+        sf.analyze(n, Cp, Ci, Cx, np.zeros(n, dtype=np.int64), 1 << 30)     # not a permutation
+    bad = Ci.copy()
+    bad[3] = n + 5
+    with pytest.raises(sf.SparseFrameError):
+        sf.analyze(n, Cp, bad, Cx, None, 1 << 30)

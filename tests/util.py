@@ -1,0 +1,140 @@
+"""shared helpers for the test-suite"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+sf = importlib.import_module("sparse-matrix-factorization-library_amd")
+gen = sf.gen
+
+INT_ARRAYS = ("Perm", "Parent", "ColCount", "Post", "Parent0", "ColCount0", "Lp", "Li", "LTp", "LTi",
+              "Super", "SuperMap", "Sparent", "Lsip", "Lsxp", "Lsi", "LeafQueue",
+              "ST_Map", "ST_Pointer", "ST_Index", "Aoffset", "Moffset")
+INT_SCALARS = ("nfsuper", "nsuper", "nstage", "isize", "xsize", "csize", "nsleaf", "nnz")
+
+
+def nd_perm_py(nx, ny, nz, leaf=3):
+    """independent Python restatement of the grid nested dissection used by the harness:
+    longest axis (ties -> x, y, z), one-plane separator at lo + len//2, halves first (low, high),
+    separator last, boxes whose longest side is <= leaf in natural order."""
+    out = []
+
+    def emit(b):
+        (x0, x1), (y0, y1), (z0, z1) = b
+        zz, yy, xx = np.meshgrid(np.arange(z0, z1), np.arange(y0, y1), np.arange(x0, x1), indexing="ij")
+        out.append((xx + nx * (yy + ny * zz)).ravel())
+
+    def rec(b):
+        ln = [b[a][1] - b[a][0] for a in range(3)]
+        if min(ln) <= 0:
+            return
+        ax = 0
+        for a in (1, 2):
+            if ln[a] > ln[ax]:
+                ax = a
+        if ln[ax] <= leaf or ln[ax] < 3:
+            emit(b)
+            return
+        lo, hi = b[ax]
+        mid = lo + ln[ax] // 2
+        l, r, s = list(b), list(b), list(b)
+        l[ax] = (lo, mid)
+        s[ax] = (mid, mid + 1)
+        r[ax] = (mid + 1, hi)
+        rec(l)
+        rec(r)
+        emit(s)
+
+    rec([(0, nx), (0, ny), (0, nz)])
+    return np.concatenate(out).astype(np.int64)
+
+
+def small_cases():
+    """(name, n, Cp, Ci, Cx, perm, devSlotSize) -- the parity cases shared by CPU and GPU tests"""
+    cases = []
+    n, Cp, Ci, Cx = gen.laplacian_lower(8, 8)
+    cases.append(("lap2d_8x8_id", n, Cp, Ci, Cx, None, 1 << 30))
+    cases.append(("lap2d_8x8_nd", n, Cp, Ci, Cx, nd_perm_py(8, 8, 1), 1 << 30))
+    n, Cp, Ci, Cx = gen.laplacian_lower(4, 4, 4)
+    cases.append(("lap3d_4_nd", n, Cp, Ci, Cx, nd_perm_py(4, 4, 4), 1 << 30))
+    n, Cp, Ci, Cx = gen.laplacian_lower(8, 8, 8)
+    cases.append(("lap3d_8_nd", n, Cp, Ci, Cx, nd_perm_py(8, 8, 8), 1 << 30))
+    cases.append(("lap3d_8_nd_smallslot", n, Cp, Ci, Cx, nd_perm_py(8, 8, 8), 6000))
+    n, Cp, Ci, Cx = gen.laplacian_lower(16, 16, 16)
+    cases.append(("lap3d_16_nd", n, Cp, Ci, Cx, nd_perm_py(16, 16, 16), 1 << 30))
+    n, Cp, Ci, Cx = gen.laplacian_lower(30, 17)
+    cases.append(("lap2d_30x17_nd", n, Cp, Ci, Cx, nd_perm_py(30, 17, 1), 1 << 30))
+    n, Cp, Ci, Cx = gen.arrow_spd_lower(40, 3)
+    cases.append(("arrow_40_3", n, Cp, Ci, Cx, None, 1 << 30))
+    n, Cp, Ci, Cx = gen.arrow_spd_lower(300, 1)
+    cases.append(("arrow_300_1", n, Cp, Ci, Cx, None, 1 << 30))
+    n, Cp, Ci, Cx = gen.random_spd_lower(200, 3, seed=1)
+    cases.append(("rand_200", n, Cp, Ci, Cx, None, 1 << 30))
+    n, Cp, Ci, Cx = gen.random_spd_lower(500, 2, seed=2, bandwidth=20)
+    cases.append(("band_500", n, Cp, Ci, Cx, np.random.default_rng(7).permutation(500), 1 << 30))
+    # block diagonal: several roots
+    blocks = [gen.laplacian_lower(5, 5), gen.laplacian_lower(3, 3, 3), gen.arrow_spd_lower(10, 1)]
+    n = sum(b[0] for b in blocks)
+    Cp = [0]
+    Ci, Cx = [], []
+    off = 0
+    for bn, bCp, bCi, bCx in blocks:
+        Cp.extend((bCp[1:] + Cp[-1]).tolist())
+        Ci.append(bCi + off)
+        Cx.append(bCx)
+        off += bn
+    cases.append(("blockdiag", n, np.array(Cp, dtype=np.int64), np.concatenate(Ci), np.concatenate(Cx), None, 1 << 30))
+    # dense (one big supernode) and trivial sizes
+    nd_ = 70
+    A = np.random.default_rng(3).uniform(-1, 1, (nd_, nd_))
+    A = A @ A.T + nd_ * np.eye(nd_)
+    rows, cols = np.tril_indices(nd_)
+    order = np.lexsort((rows, cols))
+    rows, cols = rows[order], cols[order]
+    Cp = np.zeros(nd_ + 1, dtype=np.int64)
+    np.add.at(Cp, cols + 1, 1)
+    cases.append(("dense_70", nd_, np.cumsum(Cp), rows.astype(np.int64), A[rows, cols], None, 1 << 30))
+    cases.append(("one_by_one", 1, np.array([0, 1]), np.array([0]), np.array([4.0]), None, 1 << 30))
+    cases.append(("diagonal_5", 5, np.arange(6), np.arange(5), np.arange(1.0, 6.0), None, 1 << 30))
+    return cases
+
+
+def dense_reference_factor(sym):
+    """dense LAPACK Cholesky of the permuted matrix described by (Lp, Li, Lx)"""
+    n = sym.n if not isinstance(sym, dict) else sym["n"]
+    g = (lambda k: sym[k]) if isinstance(sym, dict) else (lambda k: getattr(sym, k))
+    Lp, Li, Lx = np.asarray(g("Lp")), np.asarray(g("Li")), np.asarray(g("Lx"))
+    A = np.zeros((n, n))
+    for j in range(n):
+        for p in range(Lp[j], Lp[j + 1]):
+            A[Li[p], j] = Lx[p]
+            A[j, Li[p]] = Lx[p]
+    return A, np.linalg.cholesky(A)
+
+
+def panel_entries_from_dense(sym, L):
+    """the values the supernodal layout must hold, taken from a dense factor"""
+    g = (lambda k: sym[k]) if isinstance(sym, dict) else (lambda k: getattr(sym, k))
+    Super, Lsip, Lsi, Lsxp = (np.asarray(g(k)) for k in ("Super", "Lsip", "Lsi", "Lsxp"))
+    out = np.zeros(int(g("xsize")))
+    for s in range(int(g("nsuper"))):
+        nscol = Super[s + 1] - Super[s]
+        nsrow = Lsip[s + 1] - Lsip[s]
+        rows = Lsi[Lsip[s]:Lsip[s + 1]]
+        for c in range(nscol):
+            out[Lsxp[s] + c * nsrow: Lsxp[s] + (c + 1) * nsrow] = L[rows, Super[s] + c]
+    return out
+
+
+def rel_err(a, b, mask=None):
+    a, b = np.asarray(a), np.asarray(b)
+    if mask is not None:
+        a, b = a[mask], b[mask]
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
