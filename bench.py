@@ -119,6 +119,11 @@ def main():
                            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                            "kernel_ms": round(upd_ms, 3), "panel_ms": round(plan.stat("last_panel_ms"), 3),
                            "load_ms": round(plan.stat("last_load_ms"), 3),
+                           "potrf_ms": round(plan.stat("last_potrf_ms"), 3), "trsm_ms": round(plan.stat("last_trsm_ms"), 3),
+                           "inner_gemm_ms": round(plan.stat("last_inner_gemm_ms"), 3),
+                           "outer_gemm_ms": round(plan.stat("last_outer_gemm_ms"), 3),
+                           "flops_outer_gemm": plan.stat("flops_outer_gemm"),
+                           "flops_panel_gemm": plan.stat("flops_panel_gemm"),
                            "flops_update": plan.stat("flops_update"),
                            "launches": int(plan.stat("launches")), "levels": int(plan.stat("levels"))}
 

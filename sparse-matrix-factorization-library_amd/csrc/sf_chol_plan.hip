@@ -7,10 +7,12 @@
 //
 //   memset(Lsx) ; k_load_panels                                          (loadA, C:1998-2028)
 //   for level l = 0 .. L-1:
-//       for t = 0 .. ceil(max nscol / 64)-1:          in-panel right-looking blocked factorization
-//           k_potrf_block  on every panel of the level with nscol > 64 t
-//           k_trsm_block   on the rows below that block
-//           k_gemm<0>      trailing update of the remaining panel columns  (K = 64)
+//       for every outer block column J (512 columns) of the panels of the level:
+//           k_gemm<0>      left-looking update of the block column by all columns to its left (K = J)
+//           for t = 0 .. 7:                            right-looking 64-column steps inside the block
+//               k_potrf_block  64x64 diagonal block of every panel that still has one
+//               k_trsm_block   rows below that block
+//               k_gemm<0>      trailing update of the rest of the OUTER block column (K = 64)
 //       k_gemm<1>          every (supernode of the level -> ancestor) Schur update, scatter fused
 //
 // A supernode's updates are pushed to all its ancestors as soon as it is factored (right-looking);
@@ -35,9 +37,11 @@ using sf::TrsmTask;
 namespace {
 
 struct Launch {
-    int kind;       // 0 potrf, 1 trsm, 2 gemm panel, 3 gemm scatter
+    int kind;       // 0 potrf, 1 trsm, 2 gemm panel (inner, K = NB), 3 gemm scatter, 4 gemm panel (outer, large K)
     int64_t first;  // first task
     int count;
+    int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
+    uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
 };
 
 #define HIP_TRY(expr)                                                                       \
@@ -83,16 +87,18 @@ struct sf_chol_plan {
     TrsmTask* d_trsm = nullptr;
     GemmProb* d_probs = nullptr;
     GemmTask* d_gtasks = nullptr;
+    uint32_t* d_ktprefix = nullptr;
 
     std::vector<Launch> launches;
     int nlevels = 0;
     int64_t n_gemm_tasks = 0, n_pairs = 0;
-    double flops_exec = 0, flops_update = 0, scatter_elems = 0, flops_panel_gemm = 0;
+    double flops_exec = 0, flops_update = 0, scatter_elems = 0, flops_panel_gemm = 0, flops_outer_gemm = 0;
     size_t bytes_device = 0;
     bool values_set = false;
 
     bool profiling = false;
     double last_ms = 0, last_load_ms = 0, last_panel_ms = 0, last_update_ms = 0;
+    double last_kind_ms[5] = {0, 0, 0, 0, 0};
     int last_status = SF_OK;
 
     // host copies needed by the device solve
@@ -113,7 +119,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
-                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks};
+                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks, p->d_ktprefix};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -185,47 +191,83 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
     std::vector<TrsmTask> trsm;
     std::vector<GemmProb> probs;
     std::vector<GemmTask> gtasks;
+    // Tiles of one problem are emitted in "supertile" order: blocks of (up to) 8 tile columns x 8 tile rows.
+    // The kernel hands each XCD a contiguous run of tasks, so the ~64 workgroups resident on one XCD at a
+    // time work on one supertile and march through K together: per K step they touch 8 + 8 operand slices
+    // instead of 1 + 64, i.e. each slice is fetched into that XCD's L2 once and re-used 8 times.
     auto add_tiles = [&](int32_t prob_id, int M, int N) {
         const int tmn = (M + sf::GEMM_BM - 1) / sf::GEMM_BM, tnn = (N + sf::GEMM_BN - 1) / sf::GEMM_BN;
-        for (int tn = 0; tn < tnn; ++tn)
-            for (int tm = 0; tm < tmn; ++tm) {
-                // keep tiles that contain at least one element with ci >= cj
-                if ((tm + 1) * sf::GEMM_BM - 1 < tn * sf::GEMM_BN) continue;
-                gtasks.push_back(GemmTask{prob_id, (uint16_t)tm, (uint16_t)tn});
-            }
+        const int sw = std::min(tnn, 8), sh = std::max(1, 64 / sw);
+        for (int sj = 0; sj < tnn; sj += sw)
+            for (int si = 0; si < tmn; si += sh)
+                for (int tn = sj; tn < std::min(sj + sw, tnn); ++tn)
+                    for (int tm = si; tm < std::min(si + sh, tmn); ++tm) {
+                        // keep tiles that contain at least one element with ci >= cj
+                        if ((tm + 1) * sf::GEMM_BM - 1 < tn * sf::GEMM_BN) continue;
+                        gtasks.push_back(GemmTask{prob_id, (uint16_t)tm, (uint16_t)tn});
+                    }
     };
 
     for (int l = 0; l < nlevels; ++l) {
         const std::vector<sf_long>& Sl = by_level[l];
         sf_long maxcol = 0;
         for (sf_long s : Sl) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
-        const int nsteps = (int)((maxcol + sf::NB - 1) / sf::NB);
-        for (int t = 0; t < nsteps; ++t) {
-            const int64_t p0 = (int64_t)potrf.size(), t0 = (int64_t)trsm.size(), g0 = (int64_t)gtasks.size();
-            for (sf_long s : Sl) {
-                const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
-                const int diag = t * sf::NB;
-                if (diag >= nscol) continue;
-                const int b = std::min(sf::NB, nscol - diag);
-                potrf.push_back(PotrfTask{Lsxp[s], nsrow, diag, b, 0});
-                const int below = diag + b;
-                for (int r = below; r < nsrow; r += sf::TRSM_ROWS)
-                    trsm.push_back(TrsmTask{Lsxp[s], nsrow, diag, b, r, std::min(sf::TRSM_ROWS, nsrow - r), 0});
-                if (below < nscol) {
+        // Two-level blocking of the in-panel factorization.  Outer block columns of OUTER_NB columns are
+        // brought up to date left-looking with ONE large-K GEMM (K = all columns to their left), then
+        // factored right-looking in NB-column steps whose trailing update stays inside the outer block.
+        // The K = NB updates are HBM-bound read-modify-writes; confining them to OUTER_NB columns cuts
+        // their traffic by n / OUTER_NB, the rest of the flops run at large K out of LDS/registers.
+        const int nouter = (int)((maxcol + sf::OUTER_NB - 1) / sf::OUTER_NB);
+        for (int jo = 0; jo < nouter; ++jo) {
+            const int J = jo * sf::OUTER_NB;
+            if (jo > 0) {
+                const int64_t g0 = (int64_t)gtasks.size();
+                for (sf_long s : Sl) {
+                    const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                    if (J >= nscol) continue;
                     GemmProb g{};
-                    g.y_off = Lsxp[s] + below + (int64_t)diag * nsrow;
+                    g.y_off = Lsxp[s] + J;            // rows J.. , columns 0..J-1
                     g.x_off = g.y_off;
-                    g.c_off = Lsxp[s] + below + (int64_t)below * nsrow;
+                    g.c_off = Lsxp[s] + J + (int64_t)J * nsrow;
                     g.lda = nsrow; g.ldc = nsrow;
-                    g.M = nsrow - below; g.N = nscol - below; g.K = b;
+                    g.M = nsrow - J; g.N = std::min(sf::OUTER_NB, nscol - J); g.K = J;
+                    p->flops_outer_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
                     p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
                     probs.push_back(g);
                     add_tiles((int32_t)probs.size() - 1, g.M, g.N);
                 }
+                if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
             }
-            if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
-            if ((int64_t)trsm.size() > t0) p->launches.push_back(Launch{1, t0, (int)(trsm.size() - t0)});
-            if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
+            const int ninner = sf::OUTER_NB / sf::NB;
+            for (int ti = 0; ti < ninner; ++ti) {
+                const int diag = J + ti * sf::NB;
+                if (diag >= maxcol) break;
+                const int64_t p0 = (int64_t)potrf.size(), t0 = (int64_t)trsm.size(), g0 = (int64_t)gtasks.size();
+                for (sf_long s : Sl) {
+                    const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                    if (diag >= nscol) continue;
+                    const int b = std::min(sf::NB, nscol - diag);
+                    const int outer_end = std::min(J + sf::OUTER_NB, nscol);
+                    potrf.push_back(PotrfTask{Lsxp[s], nsrow, diag, b, 0});
+                    const int below = diag + b;
+                    for (int r = below; r < nsrow; r += sf::TRSM_ROWS)
+                        trsm.push_back(TrsmTask{Lsxp[s], nsrow, diag, b, r, std::min(sf::TRSM_ROWS, nsrow - r), 0});
+                    if (below < outer_end) {
+                        GemmProb g{};
+                        g.y_off = Lsxp[s] + below + (int64_t)diag * nsrow;
+                        g.x_off = g.y_off;
+                        g.c_off = Lsxp[s] + below + (int64_t)below * nsrow;
+                        g.lda = nsrow; g.ldc = nsrow;
+                        g.M = nsrow - below; g.N = outer_end - below; g.K = b;
+                        p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
+                        probs.push_back(g);
+                        add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                    }
+                }
+                if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
+                if ((int64_t)trsm.size() > t0) p->launches.push_back(Launch{1, t0, (int)(trsm.size() - t0)});
+                if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
+            }
         }
         // Schur updates of every supernode of this level into its ancestors
         const int64_t g0 = (int64_t)gtasks.size();
@@ -266,6 +308,21 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
     }
     p->n_gemm_tasks = (int64_t)gtasks.size();
 
+    // K-step prefix of every GEMM launch (stream-K work distribution, see k_gemm)
+    std::vector<uint32_t> ktprefix;
+    for (Launch& L : p->launches) {
+        if (L.kind < 2) continue;
+        L.prefix_first = (int64_t)ktprefix.size();
+        uint64_t run = 0;
+        for (int k = 0; k < L.count; ++k) {
+            ktprefix.push_back((uint32_t)run);
+            run += (uint64_t)((probs[gtasks[L.first + k].prob].K + sf::GEMM_BK - 1) / sf::GEMM_BK);
+        }
+        if (run >= (uint64_t)0x7fffffff) { delete p; return SF_ERR_ARG; }   // one launch holds < 2^31 units
+        ktprefix.push_back((uint32_t)run);
+        L.units = (uint32_t)run;
+    }
+
     // ---------------- upload ----------------
     std::vector<int32_t> Li32(p->nnz), Super32(nsuper + 1), SuperMap32(n), Lsi32(p->isize);
     for (sf_long k = 0; k < p->nnz; ++k) Li32[k] = (int32_t)Li[k];
@@ -290,6 +347,7 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
         if ((rc = upload(&p->d_trsm, trsm, &p->bytes_device))) break;
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
         const size_t xb = std::max<int64_t>(p->xsize, 1) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
             hipMalloc((void**)&p->d_info, sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
@@ -344,8 +402,9 @@ int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
         switch (L.kind) {
             case 0: sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st); break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
-            case 2: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, L.count, 0, p->d_Lsx, p->d_Lsi, st); break;
-            case 3: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, L.count, 1, p->d_Lsx, p->d_Lsi, st); break;
+            case 2:
+            case 4: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 0, p->d_Lsx, p->d_Lsi, st); break;
+            case 3: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 1, p->d_Lsx, p->d_Lsi, st); break;
         }
         if (p->profiling) { kinds.push_back(L.kind); mark(); }
     }
@@ -354,11 +413,13 @@ int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
     if (p->profiling) {
         HIP_TRY(hipStreamSynchronize(st));
         p->last_load_ms = p->last_panel_ms = p->last_update_ms = 0;
+        for (double& v : p->last_kind_ms) v = 0;
         float ms = 0;
         if (!evs.empty() && hipEventElapsedTime(&ms, p->ev0, evs[0]) == hipSuccess) p->last_load_ms = ms;
         for (size_t k = 0; k + 1 < evs.size(); ++k) {
             if (hipEventElapsedTime(&ms, evs[k], evs[k + 1]) != hipSuccess) continue;
             if (kinds[k] == 3) p->last_update_ms += ms; else p->last_panel_ms += ms;
+            p->last_kind_ms[kinds[k]] += ms;
         }
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
@@ -398,6 +459,11 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     if (k == "last_load_ms") return p->last_load_ms;
     if (k == "last_panel_ms") return p->last_panel_ms;
     if (k == "last_update_ms") return p->last_update_ms;
+    if (k == "last_potrf_ms") return p->last_kind_ms[0];
+    if (k == "last_trsm_ms") return p->last_kind_ms[1];
+    if (k == "last_inner_gemm_ms") return p->last_kind_ms[2];
+    if (k == "last_outer_gemm_ms") return p->last_kind_ms[4];
+    if (k == "flops_outer_gemm") return p->flops_outer_gemm;
     return -1;
 }
 

@@ -6,10 +6,12 @@
 namespace sf {
 
 constexpr int NB = 64;          // diagonal block size of the in-panel right-looking factorization
+constexpr int OUTER_NB = 512;      // outer (left-looking) block-column width of the two-level panel factorization
 constexpr int TRSM_ROWS = 256;  // rows per TRSM workgroup (one row per lane)
 constexpr int GEMM_BM = 128;    // tile extent along ci (target rows; contiguous in memory)
 constexpr int GEMM_BN = 128;    // tile extent along cj (target columns)
 constexpr int GEMM_BK = 16;
+constexpr int GEMM_GRID = 512;   // persistent GEMM grid: 2 workgroups per CU x 256 CUs
 
 // One C -= Y * X^T problem on rows of ONE source panel (column-major, leading dimension lda):
 //   C[ci][cj] = sum_k src[y_off + ci + k*lda] * src[x_off + cj + k*lda],   0<=ci<M, 0<=cj<N, 0<=k<K
@@ -53,8 +55,9 @@ void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, 
                         const int64_t* Lsxp, double* Lsx, hipStream_t st);
 void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st);
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
-void launch_gemm(const GemmProb* probs, const GemmTask* tasks, int ntasks, int mode, double* Lsx,
-                 const int32_t* Lsi, hipStream_t st);
+// kt_prefix[0..ntasks]: running count of 16-deep K steps of the launch's tiles (kt_prefix[ntasks] = total_units)
+void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
+                 int mode, double* Lsx, const int32_t* Lsi, hipStream_t st, int ablate = 0);
 
 // device-side supernodal triangular solves (one launch per level of the supernodal tree)
 struct SolveTask {

@@ -63,52 +63,54 @@ void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Cholesky of a b x b (b <= 64) diagonal block, lower, in LDS.  One workgroup of 256 lanes per block.
+// Cholesky of a b x b (b <= 64) diagonal block, lower.  ONE wavefront per block, no LDS, no barrier:
+// lane r keeps row r of the block in registers (a[c] = A(r,c)); at step j the pivot and the multipliers
+// l(c,j) are broadcast out of lane j / lane c with v_readlane (the lane index is a compile-time
+// constant after unrolling, so the broadcast lands in SGPRs and feeds v_fma_f64 directly).
+// Rows/columns beyond b are padded with the identity.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64)
 k_potrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ info) {
-    __shared__ double D[NB][NB + 1];   // D[col][row]
     const PotrfTask t = tasks[blockIdx.x];
     double* A = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
     const int b = t.b;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t ld = t.ld;
 
-    for (int e = tid; e < b * NB; e += 256) {
-        const int c = e / NB, r = e % NB;
-        if (r < b) D[c][r] = (r >= c) ? A[r + (int64_t)c * t.ld] : 0.0;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        double v = (c == lane) ? 1.0 : 0.0;
+        if (lane < b && c <= lane) v = A[lane + c * ld];
+        a[c] = v;
     }
-    __syncthreads();
-
-    for (int j = 0; j < b; ++j) {
-        const double djj = D[j][j];
-        if (tid == 0 && !(djj > 0.0)) atomicExch(info, 1);   // not positive definite (also catches NaN)
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double djj = readlane_f64(a[j], j);
+        bad = bad || !(djj > 0.0);          // also catches NaN; padded rows have djj = 1
         const double d = sqrt(djj);
         const double rinv = 1.0 / d;
-        __syncthreads();
-        // scale column j
-        if (tid < b - j) {
-            const int r = j + tid;
-            D[j][r] = (tid == 0) ? d : D[j][r] * rinv;
-        }
-        __syncthreads();
-        // trailing rank-1 update of the lower triangle: (r, c), j < c <= r < b
-        const int m = b - j - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            const int c = j + 1 + e / m, r = j + 1 + e % m;
-            if (r >= c) D[c][r] -= D[j][r] * D[j][c];
-        }
-        __syncthreads();
+        const double lj = (lane == j) ? d : ((lane > j) ? a[j] * rinv : 0.0);
+        a[j] = lj;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) a[c] -= lj * readlane_f64(lj, c);
     }
-
-    for (int e = tid; e < b * NB; e += 256) {
-        const int c = e / NB, r = e % NB;
-        if (r < b && r >= c) A[r + (int64_t)c * t.ld] = D[c][r];
-    }
+    if (bad && lane == 0) atomicExch(info, 1);
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+        if (lane < b && c <= lane) A[lane + c * ld] = a[c];
 }
 
 void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st) {
     if (ntasks <= 0) return;
-    hipLaunchKernelGGL(k_potrf_block, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, info);
+    hipLaunchKernelGGL(k_potrf_block, dim3(ntasks), dim3(64), 0, st, tasks, Lsx, info);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -179,145 +181,199 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st)
 // ---------------------------------------------------------------------------------------------------
 constexpr int LDS_LD = GEMM_BM + 16;
 
+// largest i in [0, n) with a[i] <= key   (a ascending, a[0] = 0 <= key)
+__device__ __forceinline__ int last_le_u32(const uint32_t* __restrict__ a, int n, uint32_t key) {
+    int lo = 0, hi = n;     // invariant: a[lo] <= key, (hi == n or a[hi] > key)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= key) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Persistent "stream-K" launch: the work of one launch is the list of (tile, 16-deep K step) units of all
+// its tiles, in task order; kt_prefix[i] = number of units before tile i.  The grid is a fixed number of
+// workgroups (2 per CU); each takes one contiguous, equal share of the units, so that the chip stays full
+// whatever the mix of tile counts and K lengths in the launch (no tail of half-empty rounds).  A tile
+// whose K range is split between workgroups is combined with fp64 atomics in the epilogue.
 template <int MODE>
 __global__ void __launch_bounds__(256, 2)
-k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks, int ntasks,
-       double* __restrict__ Lsx, const int32_t* __restrict__ Lsi) {
+k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
+       const uint32_t* __restrict__ kt_prefix, int ntasks,
+       double* __restrict__ Lsx, const int32_t* __restrict__ Lsi, int ablate) {
     __shared__ double Ys[2][GEMM_BK][LDS_LD];
     __shared__ double Xs[2][GEMM_BK][LDS_LD];
     __shared__ int32_t rowmap[GEMM_BM];
     __shared__ int32_t colmap[GEMM_BN];
 
-    // XCD-aware order: workgroups b, b+8, b+16 ... share an XCD (and its L2); give each XCD a
-    // contiguous run of tasks so that tiles of one problem re-use the operand panels from one L2.
-    int task_id;
-    {
-        const int b = blockIdx.x, q = ntasks >> 3, r = ntasks & 7, x = b & 7;
-        task_id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
-    const GemmTask tk = tasks[task_id];
-    const GemmProb pb = probs[tk.prob];
-    const int ci0 = tk.tm * GEMM_BM, cj0 = tk.tn * GEMM_BN;
-    const int M = pb.M, N = pb.N, K = pb.K;
-    const int lda = pb.lda;
-    const double* __restrict__ Yg = Lsx + pb.y_off + ci0;
-    const double* __restrict__ Xg = Lsx + pb.x_off + cj0;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-
-    if (MODE == 1) {
-        // relative map of this tile's rows/columns inside the target panel
-        if (tid < GEMM_BM) {
-            const int ci = ci0 + tid;
-            int32_t v = 0;
-            if (ci < M) {
-                const int32_t g = Lsi[pb.src_rows + ci];
-                v = (ci < N) ? (g - pb.tgt_first_col)
-                             : pb.tgt_nscol + lower_bound_i32(Lsi + pb.tgt_rows, pb.tgt_nbelow, g);
-            }
-            rowmap[tid] = v;
-        } else {
-            const int cj = cj0 + (tid - GEMM_BM);
-            colmap[tid - GEMM_BM] = (cj < N) ? (Lsi[pb.src_rows + cj] - pb.tgt_first_col) : 0;
-        }
-    }
-
-    // global -> register staging: lane handles row (tid & 127), k = (tid >> 7) + 2*q, q = 0..7
-    const int lrow = tid & 127, lk0 = tid >> 7;
-    const bool yrow_ok = (ci0 + lrow) < M, xrow_ok = (cj0 + lrow) < N;
-    double ry[8], rx[8];
-
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + lk0 + 2 * q;
-            const bool kin = k < K;
-            ry[q] = (yrow_ok && kin) ? Yg[lrow + (int64_t)k * lda] : 0.0;
-            rx[q] = (xrow_ok && kin) ? Xg[lrow + (int64_t)k * lda] : 0.0;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            Ys[buf][lk0 + 2 * q][lrow] = ry[q];
-            Xs[buf][lk0 + 2 * q][lrow] = rx[q];
-        }
-    };
-
-    // a wave whose 64x64 quadrant lies entirely outside the lower trapezoid does no MFMA work
-    const int qci0 = ci0 + wm * 64, qcj0 = cj0 + wn * 64;
-    const bool quad_active = (qci0 < M) && (qcj0 < N) && (qci0 + 63 >= qcj0);
-
-    double4_t acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
     const int fr = lane & 15, fk = lane >> 4;
-    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
-    load_tile(0);
-    int buf = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        store_tile(buf);
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile((kt + 1) * GEMM_BK);
-        if (quad_active) {
-#pragma unroll
-            for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
-                double a[4], b[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a[t] = Xs[buf][kk * 4 + fk][wn * 64 + t * 16 + fr];
-                    b[t] = Ys[buf][kk * 4 + fk][wm * 64 + t * 16 + fr];
+    const int lrow = tid & 127, lk0 = tid >> 7;
+
+    // XCD-aware share: workgroups b, b+8, b+16 ... run on one XCD (one L2); give each XCD a contiguous
+    // run of shares so that the tiles it works on at any time are neighbours (supertile order).
+    const uint32_t T = kt_prefix[ntasks];
+    const uint32_t G = gridDim.x;
+    uint32_t share;
+    {
+        const uint32_t b = blockIdx.x, q = G >> 3, r = G & 7, x = b & 7;
+        share = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const uint32_t U = (T + G - 1) / G;
+    uint32_t u = share * U;
+    if (u >= T) return;
+    const uint32_t u_end = min(T, u + U);
+    int ti = last_le_u32(kt_prefix, ntasks + 1, u);
+
+    while (u < u_end) {
+        const GemmTask tk = tasks[ti];
+        const GemmProb pb = probs[tk.prob];
+        const uint32_t tbase = kt_prefix[ti];
+        const int nkt = (int)(kt_prefix[ti + 1] - tbase);
+        const int kt0 = (int)(u - tbase);
+        const int kt1 = min(nkt, kt0 + (int)(u_end - u));
+        const bool partial = (kt0 > 0) || (kt1 < nkt);
+        u += (uint32_t)(kt1 - kt0);
+        ++ti;
+
+        const int ci0 = tk.tm * GEMM_BM, cj0 = tk.tn * GEMM_BN;
+        const int M = pb.M, N = pb.N, K = pb.K;
+        const int lda = pb.lda;
+        const double* __restrict__ Yg = Lsx + pb.y_off + ci0;
+        const double* __restrict__ Xg = Lsx + pb.x_off + cj0;
+
+        if (MODE == 1) {
+            // relative map of this tile's rows/columns inside the target panel
+            if (tid < GEMM_BM) {
+                const int ci = ci0 + tid;
+                int32_t v = 0;
+                if (ci < M) {
+                    const int32_t g = Lsi[pb.src_rows + ci];
+                    v = (ci < N) ? (g - pb.tgt_first_col)
+                                 : pb.tgt_nscol + lower_bound_i32(Lsi + pb.tgt_rows, pb.tgt_nbelow, g);
                 }
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                rowmap[tid] = v;
+            } else {
+                const int cj = cj0 + (tid - GEMM_BM);
+                colmap[tid - GEMM_BM] = (cj < N) ? (Lsi[pb.src_rows + cj] - pb.tgt_first_col) : 0;
             }
         }
-        buf ^= 1;
-    }
 
-    if (!quad_active) return;
-    double* __restrict__ Cg = Lsx + pb.c_off;
-    const int64_t ldc = pb.ldc;
+        // global -> register staging: lane handles row (tid & 127), k = (tid >> 7) + 2*q, q = 0..7.
+        // Loads are unconditional (row clamped to a valid one, zeroed when staged into LDS); only the
+        // last, partial K step of a problem takes the masked path.
+        const bool yrow_ok = (ci0 + lrow) < M, xrow_ok = (cj0 + lrow) < N;
+        const double* __restrict__ yp = Yg + (yrow_ok ? lrow : 0) + (int64_t)lk0 * lda;
+        const double* __restrict__ xp = Xg + (xrow_ok ? lrow : 0) + (int64_t)lk0 * lda;
+        const int64_t qstride = 2 * (int64_t)lda;
+        double ry[8], rx[8];
+
+        auto load_tile = [&](int k0) {
+            const double* __restrict__ y = yp + (int64_t)k0 * lda;
+            const double* __restrict__ x = xp + (int64_t)k0 * lda;
+            if (k0 + GEMM_BK <= K) {
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
+                for (int q = 0; q < 8; ++q) {
+                    ry[q] = y[q * qstride];
+                    rx[q] = x[q * qstride];
+                }
+            } else {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int lci = wm * 64 + tn * 16 + fr;
-            const int ci = ci0 + lci;
+                for (int q = 0; q < 8; ++q) {
+                    const bool kin = (k0 + lk0 + 2 * q) < K;
+                    const int64_t off = kin ? q * qstride : 0;
+                    const double vy = y[off], vx = x[off];
+                    ry[q] = kin ? vy : 0.0;
+                    rx[q] = kin ? vx : 0.0;
+                }
+            }
+        };
+        auto store_tile = [&](int buf) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lcj = wn * 64 + tm * 16 + fk + 4 * r;
-                const int cj = cj0 + lcj;
-                if (ci < M && cj < N && ci >= cj) {
-                    const double v = acc[tm][tn][r];
-                    if (MODE == 1) {
-                        double* dst = Cg + rowmap[lci] + (int64_t)colmap[lcj] * ldc;
-                        unsafeAtomicAdd(dst, -v);
-                    } else {
-                        double* dst = Cg + ci + (int64_t)cj * ldc;
-                        *dst -= v;
+            for (int q = 0; q < 8; ++q) {
+                Ys[buf][lk0 + 2 * q][lrow] = yrow_ok ? ry[q] : 0.0;
+                Xs[buf][lk0 + 2 * q][lrow] = xrow_ok ? rx[q] : 0.0;
+            }
+        };
+
+        // a wave whose 64x64 quadrant lies entirely outside the lower trapezoid does no MFMA work
+        const int qci0 = ci0 + wm * 64, qcj0 = cj0 + wn * 64;
+        const bool quad_active = (qci0 < M) && (qcj0 < N) && (qci0 + 63 >= qcj0);
+
+        double4_t acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+        load_tile(kt0 * GEMM_BK);
+        int buf = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            // `ablate` is 0 in the product; tools/gemm_bench sets bits to time the loop without one of its
+            // parts (1: no global loads after the first step, 2: no LDS staging stores, 4: no barrier)
+            if (!(ablate & 2) || kt == kt0) store_tile(buf);
+            if (!(ablate & 4) || kt == kt0) __syncthreads();
+            if (kt + 1 < kt1 && (!(ablate & 1))) load_tile((kt + 1) * GEMM_BK);
+            if (quad_active) {
+#pragma unroll
+                for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
+                    double a[4], b[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        a[t] = Xs[buf][kk * 4 + fk][wn * 64 + t * 16 + fr];
+                        b[t] = Ys[buf][kk * 4 + fk][wm * 64 + t * 16 + fr];
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+
+        if (quad_active) {
+            double* __restrict__ Cg = Lsx + pb.c_off;
+            const int64_t ldc = pb.ldc;
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const int lci = wm * 64 + tn * 16 + fr;
+                    const int ci = ci0 + lci;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lcj = wn * 64 + tm * 16 + fk + 4 * r;
+                        const int cj = cj0 + lcj;
+                        if (ci < M && cj < N && ci >= cj) {
+                            const double v = acc[tm][tn][r];
+                            if (MODE == 1) {
+                                unsafeAtomicAdd(Cg + rowmap[lci] + (int64_t)colmap[lcj] * ldc, -v);
+                            } else {
+                                double* dst = Cg + ci + (int64_t)cj * ldc;
+                                if (partial) unsafeAtomicAdd(dst, -v); else *dst -= v;
+                            }
+                        }
                     }
                 }
             }
         }
+        // the next tile re-uses the LDS buffers and the relative maps
+        __syncthreads();
     }
 }
 
-void launch_gemm(const GemmProb* probs, const GemmTask* tasks, int ntasks, int mode, double* Lsx,
-                 const int32_t* Lsi, hipStream_t st) {
-    if (ntasks <= 0) return;
+void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
+                 int mode, double* Lsx, const int32_t* Lsi, hipStream_t st, int ablate) {
+    if (ntasks <= 0 || total_units == 0) return;
+    const uint32_t grid = total_units < (uint32_t)GEMM_GRID ? total_units : (uint32_t)GEMM_GRID;
     if (mode == 1)
-        hipLaunchKernelGGL(k_gemm<1>, dim3(ntasks), dim3(256), 0, st, probs, tasks, ntasks, Lsx, Lsi);
+        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(256), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
     else
-        hipLaunchKernelGGL(k_gemm<0>, dim3(ntasks), dim3(256), 0, st, probs, tasks, ntasks, Lsx, Lsi);
+        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(256), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
 }
 
 }  // namespace sf
