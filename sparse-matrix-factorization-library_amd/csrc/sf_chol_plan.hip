@@ -9,10 +9,10 @@
 //   for level l = 0 .. L-1:
 //       for every outer block column J (512 columns) of the panels of the level:
 //           k_gemm<0>      left-looking update of the block column by all columns to its left (K = J)
-//           for t = 0 .. 7:                            right-looking 64-column steps inside the block
+//           for t = 0 .. 7:                            64-column steps inside the block, also left-looking
+//               k_gemm<0>      update of block column t by block columns 0..t-1 of this outer block (K = 64 t)
 //               k_potrf_block  64x64 diagonal block of every panel that still has one
 //               k_trsm_block   rows below that block
-//               k_gemm<0>      trailing update of the rest of the OUTER block column (K = 64)
 //       k_gemm<1>          every (supernode of the level -> ancestor) Schur update, scatter fused
 //
 // A supernode's updates are pushed to all its ancestors as soon as it is factored (right-looking);
@@ -238,6 +238,10 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
                 }
                 if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
             }
+            // Inside the outer block the 64-column steps are LEFT-looking as well: block column t is first
+            // updated by the t block columns of this outer block already factored (K = 64 t, written once),
+            // then its diagonal block is factored and the rows below are solved.  (A right-looking trailing
+            // update would read-modify-write the rest of the outer block at every step with K = 64.)
             const int ninner = sf::OUTER_NB / sf::NB;
             for (int ti = 0; ti < ninner; ++ti) {
                 const int diag = J + ti * sf::NB;
@@ -247,26 +251,25 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
                     if (diag >= nscol) continue;
                     const int b = std::min(sf::NB, nscol - diag);
-                    const int outer_end = std::min(J + sf::OUTER_NB, nscol);
-                    potrf.push_back(PotrfTask{Lsxp[s], nsrow, diag, b, 0});
-                    const int below = diag + b;
-                    for (int r = below; r < nsrow; r += sf::TRSM_ROWS)
-                        trsm.push_back(TrsmTask{Lsxp[s], nsrow, diag, b, r, std::min(sf::TRSM_ROWS, nsrow - r), 0});
-                    if (below < outer_end) {
+                    if (ti > 0) {
                         GemmProb g{};
-                        g.y_off = Lsxp[s] + below + (int64_t)diag * nsrow;
+                        g.y_off = Lsxp[s] + diag + (int64_t)J * nsrow;     // rows diag.., columns J..diag-1
                         g.x_off = g.y_off;
-                        g.c_off = Lsxp[s] + below + (int64_t)below * nsrow;
+                        g.c_off = Lsxp[s] + diag + (int64_t)diag * nsrow;
                         g.lda = nsrow; g.ldc = nsrow;
-                        g.M = nsrow - below; g.N = outer_end - below; g.K = b;
+                        g.M = nsrow - diag; g.N = b; g.K = diag - J;
                         p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
                         probs.push_back(g);
                         add_tiles((int32_t)probs.size() - 1, g.M, g.N);
                     }
+                    potrf.push_back(PotrfTask{Lsxp[s], nsrow, diag, b, 0});
+                    const int below = diag + b;
+                    for (int r = below; r < nsrow; r += sf::TRSM_ROWS)
+                        trsm.push_back(TrsmTask{Lsxp[s], nsrow, diag, b, r, std::min(sf::TRSM_ROWS, nsrow - r), 0});
                 }
+                if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
                 if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
                 if ((int64_t)trsm.size() > t0) p->launches.push_back(Launch{1, t0, (int)(trsm.size() - t0)});
-                if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
             }
         }
         // Schur updates of every supernode of this level into its ancestors
