@@ -114,9 +114,20 @@ def main():
         plan.set_profiling(False)
         upd_ms = plan.stat("last_update_ms")
         achieved = plan.stat("flops_update") / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        # HBM traffic of that kernel: not measurable live (PMC counters need rocprofv3); taken from the committed
+        # PMC passes of this exact workload when they exist (profiles/*_pmc_traffic_128cubed.json, bytes per launch)
+        traffic = None
+        if N == 128:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_128cubed.json")))
+            if files:
+                with open(files[-1]) as f:
+                    traffic = json.load(f).get("k_gemm<1>", {}).get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<1> (Schur update, fused scatter)",
                            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "traffic_note": "HBM bytes per launch of k_gemm<1> from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                           "(profiles/, FETCH_SIZE x2 after calibration); null when no committed pass matches",
                            "kernel_ms": round(upd_ms, 3), "panel_ms": round(plan.stat("last_panel_ms"), 3),
                            "load_ms": round(plan.stat("last_load_ms"), 3),
                            "potrf_ms": round(plan.stat("last_potrf_ms"), 3), "trsm_ms": round(plan.stat("last_trsm_ms"), 3),

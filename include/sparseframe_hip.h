@@ -175,8 +175,14 @@ typedef struct sf_symbolic sf_symbolic;
 
 int sf_symbolic_create(sf_symbolic **out, sf_long n, const sf_long *Cp, const sf_long *Ci, const sf_float *Cx,
                        const sf_long *perm /* NULL = identity */, size_t devSlotSize);
+/* LU variant (reference LU/Source/SparseFrame.c:1068-2231): elimination tree / counts / row structures of the
+ * pattern of L + U^T, panels of (2*nsrow - nscol) x nscol values (L:1946).  is_symmetric != 0: Cp/Ci/Cx hold one
+ * triangle of a symmetric matrix (then U aliases L, L:2718-2729); otherwise the whole matrix in CSC.
+ * Extra arrays: Long "Up","Ui","UTp","UTi" (U by ROW and its transpose, L:1179-1282), double "Ux","UTx". */
+int sf_symbolic_create_lu(sf_symbolic **out, sf_long n, const sf_long *Cp, const sf_long *Ci, const sf_float *Cx,
+                          const sf_long *perm /* NULL = identity */, size_t devSlotSize, int is_symmetric);
 void sf_symbolic_destroy(sf_symbolic *sym);
-/* scalar outputs: "n","nnz","nfsuper","nsuper","nstage","isize","xsize","csize","nsleaf" */
+/* scalar outputs: "n","nnz","nfsuper","nsuper","nstage","isize","xsize","csize","nsleaf","lu","symmetric","unz" */
 sf_long sf_symbolic_scalar(const sf_symbolic *sym, const char *name);
 /* array outputs (borrowed pointers, valid until destroy):
  * Long arrays: "Perm","Parent","Post","ColCount","ColCount0","Lp","Li","LTp","LTi","Super","SuperMap","Sparent",
@@ -226,6 +232,26 @@ double sf_chol_plan_stat(const sf_chol_plan *plan, const char *name);
 /* 1 -> record HIP events around each phase of the next factorize calls */
 int sf_chol_plan_set_profiling(sf_chol_plan *plan, int on);
 int sf_chol_plan_destroy(sf_chol_plan *plan);
+
+/* ---- device plan for supernodal no-pivot LU (replaces L:2668-3573 + LU/Source/cuda_kernel.cu:22-176).
+ * Symbolic arrays from sf_symbolic_create_lu; Lsxp is the reference's (packed (2*nsrow-nscol) x nscol) offsets.
+ * Up/Ui = U by row; pass NULL for both when the input is symmetric (U aliases L, L:2718-2729).
+ * The reference never pivots (magma_dgetrf_nopiv L:2653, cusolverDnDgetrf with devIpiv = NULL L:3344): inputs must
+ * be factorizable without pivoting (e.g. diagonally dominant); a zero pivot returns SF_ERR_NOT_POSDEF. ---- */
+typedef struct sf_chol_plan sf_lu_plan;
+int sf_lu_plan_create(sf_lu_plan **plan, int device, sf_long n, sf_long nsuper,
+                      const sf_long *Super, const sf_long *SuperMap,
+                      const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                      const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui);
+int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *Ux /* NULL if U aliases L */);
+int sf_lu_plan_factorize(sf_lu_plan *plan, int sync);
+int sf_lu_plan_sync(sf_lu_plan *plan);
+/* D2H copy of the factor gathered into the reference layout: panel s = (2*nsrow-nscol) x nscol column-major,
+ * rows [0,nscol) packed L11\U11, [nscol,nsrow) L21, [nsrow,2*nsrow-nscol) U12^T (L:2514-2517) */
+int sf_lu_plan_get_factor(sf_lu_plan *plan, sf_float *Lsx);
+double sf_lu_plan_stat(const sf_lu_plan *plan, const char *name);
+int sf_lu_plan_set_profiling(sf_lu_plan *plan, int on);
+int sf_lu_plan_destroy(sf_lu_plan *plan);
 
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
 int sf_device_count(void);

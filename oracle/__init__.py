@@ -38,6 +38,12 @@ def _load():
         _lib.sfo_chol_solve.restype = None
         _lib.sfo_chol_residual.argtypes = [C.c_int64, _lp, _lp, _dp, C.c_int64] + [_lp] * 4 + [_dp, _dp]
         _lib.sfo_chol_residual.restype = C.c_double
+        _lib.sfo_lu_factorize.argtypes = [C.c_int64, C.c_int64] + [_lp] * 7 + [_dp, _lp, _lp, _dp, _lp, C.c_int64, C.c_int64, _dp, _dp]
+        _lib.sfo_lu_factorize.restype = C.c_int
+        _lib.sfo_lu_solve.argtypes = [C.c_int64] + [_lp] * 4 + [_dp, C.c_int64, _dp, _dp]
+        _lib.sfo_lu_solve.restype = None
+        _lib.sfo_lu_residual.argtypes = [C.c_int64, _lp, _lp, _dp, _lp, _lp, _dp, C.c_int64] + [_lp] * 4 + [_dp, _dp]
+        _lib.sfo_lu_residual.restype = C.c_double
     return _lib
 
 
@@ -137,3 +143,61 @@ def lower_mask(sym):
         for c in range(1, nscol):
             mask[base + c * nsrow: base + c * nsrow + c] = False
     return mask
+
+
+# ---------------------------------------------------------------------------------------------
+# LU (no pivoting)
+# ---------------------------------------------------------------------------------------------
+def _getter(sym):
+    return (lambda k: sym[k]) if isinstance(sym, dict) else (lambda k: getattr(sym, k))
+
+
+def _u_arrays(g):
+    """U by row; a symmetric input aliases U to L (reference LU/Source/SparseFrame.c:2718-2729)"""
+    if int(g("symmetric")):
+        return _i64(g("Lp")), _i64(g("Li")), _f64(g("Lx"))
+    return _i64(g("Up")), _i64(g("Ui")), _f64(g("Ux"))
+
+
+def lu_factorize(sym):
+    """sym from the LU analysis (lu=1).  Returns (Lsx in the reference's (2*nsrow-nscol) x nscol layout, info, stats)."""
+    lib = _load()
+    g = _getter(sym)
+    arrs = [_i64(g(k)) for k in ("Super", "SuperMap", "Lsip", "Lsi", "Lsxp", "Lp", "Li")]
+    Lx = _f64(g("Lx"))
+    Up, Ui, Ux = _u_arrays(g)
+    LeafQueue = _i64(g("LeafQueue"))
+    Lsx = np.empty(max(int(g("xsize")), 1), dtype=np.float64)
+    stats = np.zeros(5)
+    info = lib.sfo_lu_factorize(int(g("n")), int(g("nsuper")), *[a.ctypes.data_as(_lp) for a in arrs],
+                                Lx.ctypes.data_as(_dp), Up.ctypes.data_as(_lp), Ui.ctypes.data_as(_lp), Ux.ctypes.data_as(_dp),
+                                LeafQueue.ctypes.data_as(_lp), int(g("nsleaf")), int(g("csize")),
+                                Lsx.ctypes.data_as(_dp), stats.ctypes.data_as(_dp))
+    names = ("flops_gemm", "flops_getrf", "flops_trsm", "scatter_elems", "seconds")
+    return Lsx[:int(g("xsize"))], info, dict(zip(names, stats.tolist()))
+
+
+def lu_solve(sym, Lsx, b):
+    lib = _load()
+    g = _getter(sym)
+    arrs = [_i64(g(k)) for k in ("Super", "Lsip", "Lsi", "Lsxp")]
+    Lsx, b = _f64(Lsx), _f64(b)
+    x = np.empty_like(b)
+    lib.sfo_lu_solve(int(g("nsuper")), *[a.ctypes.data_as(_lp) for a in arrs], Lsx.ctypes.data_as(_dp),
+                     int(g("n")), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    return x
+
+
+def lu_residual(sym, Lsx):
+    lib = _load()
+    g = _getter(sym)
+    Lp, Li, Lx = _i64(g("Lp")), _i64(g("Li")), _f64(g("Lx"))
+    Up, Ui, Ux = _u_arrays(g)
+    arrs = [_i64(g(k)) for k in ("Super", "Lsip", "Lsi", "Lsxp")]
+    Lsx = _f64(Lsx)
+    x = np.empty(max(int(g("n")), 1))
+    r = lib.sfo_lu_residual(int(g("n")), Lp.ctypes.data_as(_lp), Li.ctypes.data_as(_lp), Lx.ctypes.data_as(_dp),
+                            Up.ctypes.data_as(_lp), Ui.ctypes.data_as(_lp), Ux.ctypes.data_as(_dp),
+                            int(g("nsuper")), *[a.ctypes.data_as(_lp) for a in arrs],
+                            Lsx.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    return float(r), x[:int(g("n"))]

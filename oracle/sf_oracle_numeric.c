@@ -12,6 +12,13 @@
  *   sfo_chol_solve            <- SparseFrame_solve_supernodal   :3036-3139
  *   sfo_chol_residual         <- SparseFrame_validate           :3141-3266
  *
+ * and the LU twins (no pivoting; reference LU/Source/SparseFrame.c, "L:"):
+ *   sfo_lu_assemble_panel     <- SparseFrame_loadA              L:2478-2536
+ *   sfo_lu_apply_descendant   <- SparseFrame_cpuApply           L:2538-2620
+ *   sfo_lu_factor_supernode   <- SparseFrame_cpuApplyFactorize  L:2622-2666  (magma_dgetrf_nopiv at L:2653 is third
+ *                                party and absent: restated as the textbook blocked right-looking no-pivot LU)
+ *   sfo_lu_factorize / sfo_lu_solve / sfo_lu_residual <- L:2668-3573 (CPU worker), L:3592-3700, L:3702-3858
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's library;
  * the product (libsparseframe_hip.so) never does.
  *
@@ -49,6 +56,9 @@ typedef void (*syrk64_t)(const char*, const char*, const Long*, const Long*, con
 typedef void (*gemm64_t)(const char*, const char*, const Long*, const Long*, const Long*, const double*, const double*, const Long*, const double*, const Long*, const double*, double*, const Long*);
 typedef void (*potrf64_t)(const char*, const Long*, double*, const Long*, Long*);
 typedef void (*trsm64_t)(const char*, const char*, const char*, const char*, const Long*, const Long*, const double*, const double*, const Long*, double*, const Long*);
+
+typedef gemm32_t gemmg32_t;
+typedef gemm64_t gemmg64_t;
 
 static struct {
     int kind; /* 0 = built-in C loops, 32 = LP64 library, 64 = ILP64 library */
@@ -177,6 +187,74 @@ static void blas_trsm(Long m, Long n, const double* A, Long lda, double* X, Long
     if (B.kind == 32) { int m_ = (int)m, n_ = (int)n, a_ = (int)lda, x_ = (int)ldx; B.trsm32("R", "L", "C", "N", &m_, &n_, &one, A, &a_, X, &x_); }
     else if (B.kind == 64) B.trsm64("R", "L", "C", "N", &m, &n, &one, A, &lda, X, &ldx);
     else c_trsm_rltn(m, n, A, lda, X, ldx);
+}
+
+/* general dgemm / dtrsm front ends used by the LU path (alpha, beta, flags as in BLAS) */
+static void blas_gemm(char ta, char tb, Long m, Long n, Long k, double alpha, const double* A, Long lda,
+                      const double* Bm, Long ldb, double beta, double* C, Long ldc) {
+    if (m <= 0 || n <= 0) return;
+    if (B.kind == 32) { int m_ = (int)m, n_ = (int)n, k_ = (int)k, a_ = (int)lda, b_ = (int)ldb, c_ = (int)ldc; B.gemm32(&ta, &tb, &m_, &n_, &k_, &alpha, A, &a_, Bm, &b_, &beta, C, &c_); return; }
+    if (B.kind == 64) { B.gemm64(&ta, &tb, &m, &n, &k, &alpha, A, &lda, Bm, &ldb, &beta, C, &ldc); return; }
+    for (Long j = 0; j < n; j++)
+        for (Long i = 0; i < m; i++) {
+            double acc = 0;
+            for (Long p = 0; p < k; p++) {
+                const double a = (ta == 'N') ? A[i + p * lda] : A[p + i * lda];
+                const double b = (tb == 'N') ? Bm[p + j * ldb] : Bm[j + p * ldb];
+                acc += a * b;
+            }
+            C[i + j * ldc] = alpha * acc + (beta == 0.0 ? 0.0 : beta * C[i + j * ldc]);
+        }
+}
+/* the three dtrsm shapes the LU path needs; built-in loops otherwise */
+static void blas_trsm_gen(char side, char uplo, char trans, char diag, Long m, Long n, const double* A, Long lda, double* X, Long ldx) {
+    const double one = 1.0;
+    if (m <= 0 || n <= 0) return;
+    if (B.kind == 32) { int m_ = (int)m, n_ = (int)n, a_ = (int)lda, x_ = (int)ldx; B.trsm32(&side, &uplo, &trans, &diag, &m_, &n_, &one, A, &a_, X, &x_); return; }
+    if (B.kind == 64) { B.trsm64(&side, &uplo, &trans, &diag, &m, &n, &one, A, &lda, X, &ldx); return; }
+    const int unit = (diag == 'U');
+    if (side == 'R' && uplo == 'L' && trans == 'T') {            /* X <- X * L^{-T} */
+        for (Long j = 0; j < n; j++) {
+            for (Long p = 0; p < j; p++) { const double a = A[j + p * lda]; for (Long i = 0; i < m; i++) X[i + j * ldx] -= X[i + p * ldx] * a; }
+            if (!unit) { const double d = A[j + j * lda]; for (Long i = 0; i < m; i++) X[i + j * ldx] /= d; }
+        }
+    } else if (side == 'R' && uplo == 'U' && trans == 'N') {     /* X <- X * U^{-1} */
+        for (Long j = 0; j < n; j++) {
+            for (Long p = 0; p < j; p++) { const double a = A[p + j * lda]; for (Long i = 0; i < m; i++) X[i + j * ldx] -= X[i + p * ldx] * a; }
+            if (!unit) { const double d = A[j + j * lda]; for (Long i = 0; i < m; i++) X[i + j * ldx] /= d; }
+        }
+    } else if (side == 'L' && uplo == 'L' && trans == 'N') {     /* X <- L^{-1} * X */
+        for (Long c = 0; c < n; c++)
+            for (Long i = 0; i < m; i++) {
+                double v = X[i + c * ldx];
+                for (Long p = 0; p < i; p++) v -= A[i + p * lda] * X[p + c * ldx];
+                X[i + c * ldx] = unit ? v : v / A[i + i * lda];
+            }
+    }
+}
+
+/* no-pivot LU of an m x n (m >= n) column-major block, blocked right-looking (stands in for magma_dgetrf_nopiv, L:2653).
+ * Returns 0 or the 1-based index of the first zero pivot. */
+static int getrf_nopiv(Long m, Long n, double* A, Long lda) {
+    const Long nb = 64;
+    for (Long k0 = 0; k0 < n; k0 += nb) {
+        const Long b = (n - k0 < nb) ? (n - k0) : nb;
+        for (Long j = k0; j < k0 + b; j++) {
+            const double piv = A[j + j * lda];
+            if (piv == 0.0 || piv != piv) return (int)(j + 1);
+            for (Long i = j + 1; i < m; i++) A[i + j * lda] /= piv;
+            for (Long c = j + 1; c < k0 + b; c++) {
+                const double u = A[j + c * lda];
+                if (u != 0.0) for (Long i = j + 1; i < m; i++) A[i + c * lda] -= A[i + j * lda] * u;
+            }
+        }
+        const Long r0 = k0 + b;
+        if (r0 < n) {
+            blas_trsm_gen('L', 'L', 'N', 'U', b, n - r0, A + k0 + k0 * lda, lda, A + k0 + r0 * lda, lda);
+            blas_gemm('N', 'N', m - r0, n - r0, b, -1.0, A + r0 + k0 * lda, lda, A + k0 + r0 * lda, lda, 1.0, A + r0 + r0 * lda, lda);
+        }
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -357,6 +435,198 @@ double sfo_chol_residual(Long n, const Long* Lp, const Long* Li, const double* L
             w[j] += fabs(Lx[p]);
             if (i != j) { r[j] += Lx[p] * x[i]; w[i] += fabs(Lx[p]); }
         }
+    double anorm = 0, bnorm = 0, xnorm = 0, rnorm = 0;
+    for (Long i = 0; i < n; i++) {
+        if (w[i] > anorm) anorm = w[i];
+        if (fabs(b[i]) > bnorm) bnorm = fabs(b[i]);
+        if (fabs(x[i]) > xnorm) xnorm = fabs(x[i]);
+        if (fabs(r[i]) > rnorm) rnorm = fabs(r[i]);
+    }
+    free(b); free(r); free(w);
+    return rnorm / (anorm * xnorm + bnorm);
+}
+
+
+/* ================================================================================================
+ * LU (no pivoting), reference LU/Source/SparseFrame.c.  Panel of supernode s: (2*nsrow - nscol) x nscol,
+ * column-major, lda = 2*nsrow - nscol: rows [0,nscol) = packed L11\U11 (unit lower), rows [nscol,nsrow) = L21,
+ * rows [nsrow, 2*nsrow-nscol) = U12^T   (L:2514-2517, L:2548).
+ * Up/Ui/Ux: U by ROW (columns j >= i); for a symmetric input the caller passes Lp/Li/Lx again (L:2718-2729).
+ * ================================================================================================ */
+typedef struct {
+    Long n, nsuper;
+    const Long *Super, *SuperMap, *Lsip, *Lsi, *Lsxp, *Lp, *Li, *Up, *Ui;
+    const double *Lx, *Ux;
+    double* Lsx;
+    Long *Head, *Next, *Lpos, *Map, *RelMap;
+    double* C;
+    double flops_gemm, flops_getrf, flops_trsm, scatter_elems;
+    int info;
+} sfo_lu_ctx;
+
+/* L:2478-2536 */
+static void sfo_lu_assemble_panel(sfo_lu_ctx* c, Long s, double* A, Long nscol, Long nsrow, Long lda) {
+    memset(A, 0, (size_t)(nscol * lda) * sizeof(double));
+    for (Long j = c->Super[s]; j < c->Super[s + 1]; j++) {
+        const Long sj = j - c->Super[s];
+        for (Long p = c->Lp[j]; p < c->Lp[j + 1]; p++) {
+            const Long i = c->Li[p];
+            if (i > j) A[sj * lda + c->Map[i]] = c->Lx[p];                       /* strictly lower: L part */
+        }
+        for (Long p = c->Up[j]; p < c->Up[j + 1]; p++) {                          /* row j of U */
+            const Long si = c->Map[c->Ui[p]];
+            if (si < nscol) A[si * lda + sj] = c->Ux[p];                          /* inside the diagonal block */
+            else (A + nsrow - nscol)[sj * lda + si] = c->Ux[p];                   /* U12^T block */
+        }
+    }
+}
+
+/* L:2538-2620 */
+static void sfo_lu_apply_descendant(sfo_lu_ctx* c, Long s, Long nscol, Long nsrow, double* A, Long d) {
+    const Long slda = 2 * nsrow - nscol;
+    const Long ndcol = c->Super[d + 1] - c->Super[d], ndrow = c->Lsip[d + 1] - c->Lsip[d];
+    const Long* drows = c->Lsi + c->Lsip[d];
+    const Long lpos = c->Lpos[d];
+    Long lpos_next = lpos;
+    while (lpos_next < ndrow && drows[lpos_next] < c->Super[s + 1]) lpos_next++;
+    const Long dn = lpos_next - lpos, dm = ndrow - lpos_next, dnm = dn + dm, dk = ndcol;
+    const Long dlda = 2 * ndrow - ndcol, dldc = dn + 2 * dm;
+    const double* Pd = c->Lsx + c->Lsxp[d];
+    for (Long di = 0; di < ndrow - lpos; di++) c->RelMap[di] = c->Map[drows[lpos + di]];
+
+    /* C1 ((dn+dm) x dn) = L_d[lpos.., :] * (U^T_d[lpos..lpos+dn, :])^T        (L:2570) */
+    blas_gemm('N', 'T', dnm, dn, dk, 1.0, Pd + lpos, dlda, Pd + (ndrow - ndcol) + lpos, dlda, 0.0, c->C, dldc);
+    /* C2 (dm x dn) = U^T_d[lpos_next.., :] * (L_d[lpos..lpos+dn, :])^T        (L:2577) */
+    if (dm > 0)
+        blas_gemm('N', 'T', dm, dn, dk, 1.0, Pd + (ndrow - ndcol) + lpos_next, dlda, Pd + lpos, dlda, 0.0, c->C + dnm, dldc);
+    c->flops_gemm += 2.0 * dnm * dn * dk + 2.0 * dm * dn * dk;
+
+    for (Long cj = 0; cj < dn; cj++) {                                           /* L:2583-2604 */
+        for (Long ci = 0; ci < dnm; ci++) {
+            A[c->RelMap[cj] * slda + c->RelMap[ci]] -= c->C[cj * dldc + ci];
+            if (ci >= dn)
+                (A + (nsrow - nscol))[c->RelMap[cj] * slda + c->RelMap[ci]] -= (c->C + dm)[cj * dldc + ci];
+        }
+    }
+    c->scatter_elems += (double)dnm * dn + (double)dm * dn;
+    if (lpos_next < ndrow) {
+        const Long anc = c->SuperMap[drows[lpos_next]];
+        c->Next[d] = c->Head[anc];
+        c->Head[anc] = d;
+    }
+    c->Lpos[d] = lpos_next;
+}
+
+/* L:2622-2666 */
+static void sfo_lu_factor_supernode(sfo_lu_ctx* c, Long s) {
+    const Long nscol = c->Super[s + 1] - c->Super[s], nsrow = c->Lsip[s + 1] - c->Lsip[s];
+    const Long slda = 2 * nsrow - nscol, sm = nsrow - nscol;
+    const Long* rows = c->Lsi + c->Lsip[s];
+    for (Long si = 0; si < nsrow; si++) c->Map[rows[si]] = si;
+    double* A = c->Lsx + c->Lsxp[s];
+    sfo_lu_assemble_panel(c, s, A, nscol, nsrow, slda);
+    while (c->Head[s] >= 0) {
+        const Long d = c->Head[s];
+        c->Head[s] = c->Next[d];
+        sfo_lu_apply_descendant(c, s, nscol, nsrow, A, d);
+    }
+    const int info = getrf_nopiv(nsrow, nscol, A, slda);                         /* L:2653 */
+    if (info && !c->info) c->info = info;
+    if (nscol < nsrow) blas_trsm_gen('R', 'L', 'T', 'U', sm, nscol, A, slda, A + nsrow, slda);   /* L:2660 */
+    c->flops_getrf += (double)nsrow * nscol * nscol - (double)nscol * nscol * nscol / 3.0;
+    c->flops_trsm += (double)sm * nscol * nscol;
+}
+
+/* stats (may be NULL): [gemm, getrf, trsm flops, scatter elems, seconds] */
+int sfo_lu_factorize(Long n, Long nsuper, const Long* Super, const Long* SuperMap,
+                     const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                     const Long* Lp, const Long* Li, const double* Lx,
+                     const Long* Up, const Long* Ui, const double* Ux,
+                     const Long* LeafQueue_in, Long nsleaf, Long csize, double* Lsx, double* stats) {
+    sfo_lu_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.n = n; c.nsuper = nsuper;
+    c.Super = Super; c.SuperMap = SuperMap; c.Lsip = Lsip; c.Lsi = Lsi; c.Lsxp = Lsxp;
+    c.Lp = Lp; c.Li = Li; c.Lx = Lx; c.Up = Up; c.Ui = Ui; c.Ux = Ux; c.Lsx = Lsx;
+    const size_t ns1 = (size_t)(nsuper > 0 ? nsuper : 1), n1 = (size_t)(n > 0 ? n : 1);
+    c.Head = malloc(ns1 * sizeof(Long)); c.Next = malloc(ns1 * sizeof(Long)); c.Lpos = malloc(ns1 * sizeof(Long));
+    Long* Nschild = calloc(ns1, sizeof(Long));
+    Long* Queue = malloc(ns1 * sizeof(Long));
+    c.Map = malloc(n1 * sizeof(Long)); c.RelMap = malloc(n1 * sizeof(Long));
+    c.C = malloc((size_t)(csize > 0 ? csize : 1) * sizeof(double));
+    if (!c.Head || !c.Next || !c.Lpos || !Nschild || !Queue || !c.Map || !c.RelMap || !c.C) return -1;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (Long s = 0; s < nsuper; s++) { c.Head[s] = -1; c.Next[s] = -1; c.Lpos[s] = 0; }
+    for (Long s = 0; s < nsuper; s++) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        if (nscol < nsrow) Nschild[SuperMap[Lsi[Lsip[s] + nscol]]]++;
+    }
+    Long head = 0, tail = nsleaf;
+    for (Long k = 0; k < nsleaf; k++) Queue[k] = LeafQueue_in[k];
+    while (head < tail) {
+        const Long s = Queue[head++];
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        sfo_lu_factor_supernode(&c, s);
+        c.Lpos[s] = nscol;
+        if (nscol < nsrow) {
+            const Long sparent = SuperMap[Lsi[Lsip[s] + nscol]];
+            c.Next[s] = c.Head[sparent];
+            c.Head[sparent] = s;
+            if (--Nschild[sparent] <= 0) Queue[tail++] = sparent;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (stats) {
+        stats[0] = c.flops_gemm; stats[1] = c.flops_getrf; stats[2] = c.flops_trsm; stats[3] = c.scatter_elems;
+        stats[4] = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    }
+    const int done = (head == nsuper);
+    free(c.Head); free(c.Next); free(c.Lpos); free(Nschild); free(Queue); free(c.Map); free(c.RelMap); free(c.C);
+    if (!done) return -2;
+    return c.info;
+}
+
+/* L:3592-3700 */
+void sfo_lu_solve(Long nsuper, const Long* Super, const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                  const double* Lsx, Long n, const double* b, double* x) {
+    memcpy(x, b, (size_t)n * sizeof(double));
+    for (Long s = 0; s < nsuper; s++) {                           /* unit-lower forward (L:3630-3652) */
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s], slda = 2 * nsrow - nscol;
+        for (Long sj = 0; sj < nscol; sj++) {
+            const Long j = Lsi[Lsip[s] + sj];
+            for (Long si = sj + 1; si < nsrow; si++) x[Lsi[Lsip[s] + si]] -= Lsx[Lsxp[s] + sj * slda + si] * x[j];
+        }
+    }
+    for (Long s = nsuper - 1; s >= 0; s--) {                       /* backward with U (L:3654-3695) */
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s], slda = 2 * nsrow - nscol;
+        for (Long sj = nscol - 1; sj >= 0; sj--) {
+            const Long j = Lsi[Lsip[s] + sj];
+            for (Long si = sj + 1; si < nscol; si++) x[j] -= Lsx[Lsxp[s] + si * slda + sj] * x[Lsi[Lsip[s] + si]];
+            for (Long si = nscol; si < nsrow; si++) x[j] -= Lsx[Lsxp[s] + (nsrow - nscol) + sj * slda + si] * x[Lsi[Lsip[s] + si]];
+            x[j] /= Lsx[Lsxp[s] + sj * slda + sj];
+        }
+    }
+}
+
+/* L:3758-3855 -- b_i = 1 + i/n; r = A x - b with A = L-part + strictly-upper U-part */
+double sfo_lu_residual(Long n, const Long* Lp, const Long* Li, const double* Lx,
+                       const Long* Up, const Long* Ui, const double* Ux,
+                       Long nsuper, const Long* Super, const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                       const double* Lsx, double* x) {
+    double* b = malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    double* r = malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    double* w = calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    for (Long i = 0; i < n; i++) b[i] = 1 + i / (double)n;
+    sfo_lu_solve(nsuper, Super, Lsip, Lsi, Lsxp, Lsx, n, b, x);
+    for (Long i = 0; i < n; i++) r[i] = -b[i];
+    for (Long j = 0; j < n; j++) {
+        for (Long p = Lp[j]; p < Lp[j + 1]; p++) { r[Li[p]] += Lx[p] * x[j]; w[j] += fabs(Lx[p]); }
+        for (Long p = Up[j]; p < Up[j + 1]; p++) {
+            const Long i = Ui[p];
+            if (i != j) { r[j] += Ux[p] * x[i]; w[i] += fabs(Ux[p]); }
+        }
+    }
     double anorm = 0, bnorm = 0, xnorm = 0, rnorm = 0;
     for (Long i = 0; i < n; i++) {
         if (w[i] > anorm) anorm = w[i];

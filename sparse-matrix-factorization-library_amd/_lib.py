@@ -26,6 +26,8 @@ lib.sf_device_count.restype = C.c_int
 
 lib.sf_symbolic_create.argtypes = [C.POINTER(C.c_void_p), C.c_int64, c_long_p, c_long_p, c_double_p, c_long_p, C.c_size_t]
 lib.sf_symbolic_create.restype = C.c_int
+lib.sf_symbolic_create_lu.argtypes = [C.POINTER(C.c_void_p), C.c_int64, c_long_p, c_long_p, c_double_p, c_long_p, C.c_size_t, C.c_int]
+lib.sf_symbolic_create_lu.restype = C.c_int
 lib.sf_symbolic_destroy.argtypes = [C.c_void_p]
 lib.sf_symbolic_destroy.restype = None
 lib.sf_symbolic_scalar.argtypes = [C.c_void_p, C.c_char_p]
@@ -59,6 +61,23 @@ lib.sf_chol_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
 lib.sf_chol_plan_set_profiling.restype = C.c_int
 lib.sf_chol_plan_destroy.argtypes = [C.c_void_p]
 lib.sf_chol_plan_destroy.restype = C.c_int
+
+lib.sf_lu_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9
+lib.sf_lu_plan_create.restype = C.c_int
+lib.sf_lu_plan_set_values.argtypes = [C.c_void_p, c_double_p, c_double_p]
+lib.sf_lu_plan_set_values.restype = C.c_int
+lib.sf_lu_plan_factorize.argtypes = [C.c_void_p, C.c_int]
+lib.sf_lu_plan_factorize.restype = C.c_int
+lib.sf_lu_plan_sync.argtypes = [C.c_void_p]
+lib.sf_lu_plan_sync.restype = C.c_int
+lib.sf_lu_plan_get_factor.argtypes = [C.c_void_p, c_double_p]
+lib.sf_lu_plan_get_factor.restype = C.c_int
+lib.sf_lu_plan_stat.argtypes = [C.c_void_p, C.c_char_p]
+lib.sf_lu_plan_stat.restype = C.c_double
+lib.sf_lu_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
+lib.sf_lu_plan_set_profiling.restype = C.c_int
+lib.sf_lu_plan_destroy.argtypes = [C.c_void_p]
+lib.sf_lu_plan_destroy.restype = C.c_int
 
 ERR_NAMES = {0: "SF_OK", 1: "SF_ERR_ARG", 2: "SF_ERR_NO_DEVICE", 3: "SF_ERR_ALLOC",
              4: "SF_ERR_NOT_POSDEF", 5: "SF_ERR_HIP"}

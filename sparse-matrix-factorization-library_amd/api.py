@@ -52,18 +52,27 @@ class Symbolic:
     """Result of the host-side symbolic analysis (flat ABI)."""
 
     LONG_ARRAYS = ("Perm", "Parent", "Parent0", "Post", "ColCount", "ColCount0", "Lp", "Li", "LTp", "LTi",
-                   "Super", "SuperMap", "Sparent", "Lsip", "Lsxp", "Lsi", "LeafQueue",
+                   "Up", "Ui", "UTp", "UTi", "Super", "SuperMap", "Sparent", "Lsip", "Lsxp", "Lsi", "LeafQueue",
                    "ST_Map", "ST_Pointer", "ST_Index", "Aoffset", "Moffset")
-    SCALARS = ("n", "nnz", "nfsuper", "nsuper", "nstage", "isize", "xsize", "csize", "nsleaf")
+    SCALARS = ("n", "nnz", "nfsuper", "nsuper", "nstage", "isize", "xsize", "csize", "nsleaf", "lu", "symmetric", "unz")
 
-    def __init__(self, n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU):
+    def __init__(self, n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU, method="cholesky", symmetric=True):
+        """method 'cholesky' (input = one triangle) or 'lu' (symmetric=True: one triangle, else the whole matrix)"""
         Cp, Ci, Cx = _i64(Cp), _i64(Ci), _f64(Cx)
         if perm is not None:
             perm = _i64(perm)
         h = C.c_void_p()
-        check(lib.sf_symbolic_create(C.byref(h), n, _lp(Cp), _lp(Ci), _dp(Cx),
-                                     _lp(perm) if perm is not None else None, dev_slot_size),
-              "sf_symbolic_create")
+        if method == "cholesky":
+            check(lib.sf_symbolic_create(C.byref(h), n, _lp(Cp), _lp(Ci), _dp(Cx),
+                                         _lp(perm) if perm is not None else None, dev_slot_size),
+                  "sf_symbolic_create")
+        elif method == "lu":
+            check(lib.sf_symbolic_create_lu(C.byref(h), n, _lp(Cp), _lp(Ci), _dp(Cx),
+                                            _lp(perm) if perm is not None else None, dev_slot_size,
+                                            1 if symmetric else 0), "sf_symbolic_create_lu")
+        else:
+            raise ValueError(method)
+        self.method = method
         self._h = h
         self._cache = {}
         self.dev_slot_size = dev_slot_size
@@ -88,7 +97,7 @@ class Symbolic:
                 self._cache[name] = (np.ctypeslib.as_array(p, shape=(ln.value,)).copy()
                                      if ln.value else np.zeros(0, np.int64))
             return self._cache[name]
-        if name in ("Lx", "LTx"):
+        if name in ("Lx", "LTx", "Ux", "UTx"):
             if name not in self._cache:
                 ln = C.c_int64()
                 p = lib.sf_symbolic_float_array(self._h, name.encode(), C.byref(ln))
@@ -114,8 +123,8 @@ class Symbolic:
         return float(lib.sf_symbolic_flops(self._h, 3))
 
 
-def analyze(n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU):
-    return Symbolic(n, Cp, Ci, Cx, perm, dev_slot_size)
+def analyze(n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU, method="cholesky", symmetric=True):
+    return Symbolic(n, Cp, Ci, Cx, perm, dev_slot_size, method, symmetric)
 
 
 class CholPlan:
@@ -164,6 +173,57 @@ class CholPlan:
     def close(self):
         if getattr(self, "_h", None):
             lib.sf_chol_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class LUPlan:
+    """Device-resident supernodal no-pivot LU (flat ABI, sf_lu_plan_*).  `sym` comes from analyze(..., method='lu')."""
+
+    def __init__(self, sym, device=0):
+        if not sym.lu:
+            raise ValueError("LUPlan needs an LU symbolic analysis (method='lu')")
+        h = C.c_void_p()
+        self._alias = bool(sym.symmetric)
+        self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
+        if not self._alias:
+            self._keep += [sym.Up, sym.Ui]
+        args = [_lp(a) for a in self._keep] + ([None, None] if self._alias else [])
+        check(lib.sf_lu_plan_create(C.byref(h), device, sym.n, sym.nsuper, *args), "sf_lu_plan_create")
+        self._h = h
+        self.xsize = sym.xsize
+        self.n = sym.n
+
+    def set_values(self, Lx, Ux=None):
+        Lx = _f64(Lx)
+        if self._alias:
+            check(lib.sf_lu_plan_set_values(self._h, _dp(Lx), None), "sf_lu_plan_set_values")
+        else:
+            Ux = _f64(Ux)
+            check(lib.sf_lu_plan_set_values(self._h, _dp(Lx), _dp(Ux)), "sf_lu_plan_set_values")
+
+    def factorize(self, sync=True):
+        check(lib.sf_lu_plan_factorize(self._h, 1 if sync else 0), "sf_lu_plan_factorize")
+
+    def sync(self):
+        check(lib.sf_lu_plan_sync(self._h), "sf_lu_plan_sync")
+
+    def get_factor(self):
+        out = np.empty(max(self.xsize, 1), dtype=np.float64)
+        check(lib.sf_lu_plan_get_factor(self._h, _dp(out)), "sf_lu_plan_get_factor")
+        return out[:self.xsize]
+
+    def stat(self, name):
+        return float(lib.sf_lu_plan_stat(self._h, name.encode()))
+
+    def set_profiling(self, on=True):
+        check(lib.sf_lu_plan_set_profiling(self._h, 1 if on else 0), "sf_lu_plan_set_profiling")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sf_lu_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

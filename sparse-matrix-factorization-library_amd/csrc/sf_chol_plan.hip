@@ -66,6 +66,15 @@ int upload(T** dptr, const std::vector<T>& h, size_t* bytes_total) {
 }  // namespace
 
 struct sf_chol_plan {
+    bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
+    int64_t xC = 0;             // doubles in one set of nsrow x nscol panels (Cholesky: == xsize)
+    int64_t unz = 0;            // LU: entries of U (by row)
+    int64_t* d_Up = nullptr;    // LU, unsymmetric input: U by row
+    int32_t* d_Ui = nullptr;
+    double* d_Ux = nullptr;
+    int64_t* d_Xp = nullptr;    // LU: offsets of the nsrow x nscol panels (the reference's Lsxp has the packed sizes)
+    double* d_pack = nullptr;   // LU: staging buffer in the reference layout for the download
+    bool u_alias = false;       // LU with a symmetric input: U aliases L (reference L:2718-2729)
     int device = 0;
     int64_t n = 0, nsuper = 0, nnz = 0, isize = 0, xsize = 0;
     hipStream_t stream = nullptr;
@@ -119,7 +128,8 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
-                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks, p->d_ktprefix};
+                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks, p->d_ktprefix,
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -129,10 +139,20 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     return SF_OK;
 }
 
-int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
-                        const sf_long* Super, const sf_long* SuperMap,
-                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
-                        const sf_long* Lp, const sf_long* Li) {
+// Common plan builder.  lu == false: Cholesky, one nsrow x nscol panel per supernode at Lsxp[s] (the reference layout).
+// lu == true: no-pivot LU kept on the device as a PAIR of nsrow x nscol panels per supernode,
+//     PL(i,j) = L(i,j) for i > j (unit diagonal implied), PU(i,j) = U(j,i) for i >= j  (i.e. U^T),
+// all PL panels first, then all PU panels (shift xC).  With that pairing every LU operation is the Cholesky one
+// with the two operand roles taken from different panels:
+//     L-panel update   C(ci,cj) -= sum_k PL(ci,k) PU(cj,k), ci >  cj      U-panel update  C -= sum_k PU(ci,k) PL(cj,k), ci >= cj
+//     L21 <- L21 U11^{-1}  = k_trsm_block with D = PU's diagonal block    U12^T <- U12^T L11^{-T} = same kernel, D = PL's, unit
+// which are exactly the reference's two GEMMs per update (L:2570-2577), its two-target scatter (L:2583-2604) and its
+// two triangular solves (L:2653-2662), and the factor is gathered into the reference's (2*nsrow-nscol) x nscol panels
+// (L:2514-2517) only when it is downloaded.
+static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_long nsuper,
+                       const sf_long* Super, const sf_long* SuperMap,
+                       const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                       const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui) {
     if (!out) return SF_ERR_ARG;
     *out = nullptr;
     if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
@@ -148,16 +168,25 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
     sf_chol_plan* p = new (std::nothrow) sf_chol_plan();
     if (!p) return SF_ERR_ALLOC;
     p->device = device;
+    p->lu = lu;
     p->n = n;
     p->nsuper = nsuper;
     p->nnz = Lp[n];
     p->isize = Lsip[nsuper];
     p->xsize = Lsxp[nsuper];
+    p->u_alias = lu && (!Up || !Ui);
+    p->unz = (lu && !p->u_alias) ? Up[n] : 0;
+    // offsets of the nsrow x nscol panels
+    std::vector<int64_t> XP(nsuper + 1, 0);
+    for (sf_long s = 0; s < nsuper; ++s) XP[s + 1] = XP[s] + (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
+    p->xC = XP[nsuper];
+    const int64_t ushift = p->xC;     // PU(s) = PL(s) + ushift
 
     // ---------------- validate the structure the kernels index with ----------------
     for (sf_long s = 0; s < nsuper; ++s) {
         const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
-        if (nscol <= 0 || nsrow < nscol || Lsxp[s + 1] - Lsxp[s] != nscol * nsrow || nsrow >= (sf_long)0x7fffffff) {
+        const sf_long want = lu ? nscol * (2 * nsrow - nscol) : nscol * nsrow;
+        if (nscol <= 0 || nsrow < nscol || Lsxp[s + 1] - Lsxp[s] != want || nsrow >= (sf_long)0x7fffffff) {
             delete p;
             return SF_ERR_ARG;
         }
@@ -226,15 +255,21 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
                     if (J >= nscol) continue;
                     GemmProb g{};
-                    g.y_off = Lsxp[s] + J;            // rows J.. , columns 0..J-1
-                    g.x_off = g.y_off;
-                    g.c_off = Lsxp[s] + J + (int64_t)J * nsrow;
                     g.lda = nsrow; g.ldc = nsrow;
                     g.M = nsrow - J; g.N = std::min(sf::OUTER_NB, nscol - J); g.K = J;
-                    p->flops_outer_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
-                    p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
-                    probs.push_back(g);
-                    add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                    const int64_t src = XP[s] + J;                    // rows J.. , columns 0..J-1
+                    const int64_t dst = XP[s] + J + (int64_t)J * nsrow;
+                    const double fl = (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
+                    for (int side = 0; side < (lu ? 2 : 1); ++side) {     // side 0: (L) panel, side 1: U^T panel
+                        g.y_off = src + (side ? ushift : 0);
+                        g.x_off = src + ((lu && !side) ? ushift : 0);
+                        g.c_off = dst + (side ? ushift : 0);
+                        g.strict = (lu && !side) ? 1 : 0;
+                        p->flops_outer_gemm += fl;
+                        p->flops_panel_gemm += fl;
+                        probs.push_back(g);
+                        add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                    }
                 }
                 if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
             }
@@ -253,19 +288,31 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
                     const int b = std::min(sf::NB, nscol - diag);
                     if (ti > 0) {
                         GemmProb g{};
-                        g.y_off = Lsxp[s] + diag + (int64_t)J * nsrow;     // rows diag.., columns J..diag-1
-                        g.x_off = g.y_off;
-                        g.c_off = Lsxp[s] + diag + (int64_t)diag * nsrow;
                         g.lda = nsrow; g.ldc = nsrow;
                         g.M = nsrow - diag; g.N = b; g.K = diag - J;
-                        p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
-                        probs.push_back(g);
-                        add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                        const int64_t src = XP[s] + diag + (int64_t)J * nsrow;     // rows diag.., columns J..diag-1
+                        const int64_t dst = XP[s] + diag + (int64_t)diag * nsrow;
+                        for (int side = 0; side < (lu ? 2 : 1); ++side) {
+                            g.y_off = src + (side ? ushift : 0);
+                            g.x_off = src + ((lu && !side) ? ushift : 0);
+                            g.c_off = dst + (side ? ushift : 0);
+                            g.strict = (lu && !side) ? 1 : 0;
+                            p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
+                            probs.push_back(g);
+                            add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                        }
                     }
-                    potrf.push_back(PotrfTask{Lsxp[s], nsrow, diag, b, 0});
+                    potrf.push_back(PotrfTask{XP[s], nsrow, diag, b, 0});
                     const int below = diag + b;
-                    for (int r = below; r < nsrow; r += sf::TRSM_ROWS)
-                        trsm.push_back(TrsmTask{Lsxp[s], nsrow, diag, b, r, std::min(sf::TRSM_ROWS, nsrow - r), 0});
+                    for (int r = below; r < nsrow; r += sf::TRSM_ROWS) {
+                        const int nr = std::min(sf::TRSM_ROWS, nsrow - r);
+                        if (!lu) {
+                            trsm.push_back(TrsmTask{XP[s], XP[s], nsrow, diag, b, r, nr, 0});
+                        } else {
+                            trsm.push_back(TrsmTask{XP[s], XP[s] + ushift, nsrow, diag, b, r, nr, 0});            // L21 <- L21 U11^{-1}
+                            trsm.push_back(TrsmTask{XP[s] + ushift, XP[s], nsrow, diag, b, r, nr, 1});            // U12^T <- U12^T L11^{-T}
+                        }
+                    }
                 }
                 if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
                 if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
@@ -278,7 +325,8 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
             const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
             const sf_long* rows = Lsi + Lsip[s];
             const double nk = nscol;
-            p->flops_exec += nk * nk * nk / 3.0 + (double)(nsrow - nscol) * nk * nk;
+            p->flops_exec += lu ? ((double)nsrow * nk * nk - nk * nk * nk / 3.0 + (double)(nsrow - nscol) * nk * nk)
+                                : (nk * nk * nk / 3.0 + (double)(nsrow - nscol) * nk * nk);
             int i = nscol;
             while (i < nsrow) {
                 const sf_long a = SuperMap[rows[i]];
@@ -286,9 +334,6 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
                 while (e < nsrow && SuperMap[rows[e]] == a) ++e;
                 const int dn = e - i, dnm = nsrow - i;
                 GemmProb g{};
-                g.y_off = Lsxp[s] + i;
-                g.x_off = g.y_off;
-                g.c_off = Lsxp[a];
                 g.src_rows = Lsip[s] + i;
                 const int a_nscol = (int)(Super[a + 1] - Super[a]), a_nsrow = (int)(Lsip[a + 1] - Lsip[a]);
                 g.tgt_rows = Lsip[a] + a_nscol;
@@ -297,12 +342,22 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
                 g.tgt_first_col = (int32_t)Super[a];
                 g.tgt_nscol = a_nscol;
                 g.tgt_nbelow = a_nsrow - a_nscol;
-                probs.push_back(g);
-                add_tiles((int32_t)probs.size() - 1, g.M, g.N);
-                const double fl = (double)dn * (dn + 1) * nk + 2.0 * (double)(dnm - dn) * dn * nk;
+                for (int side = 0; side < (lu ? 2 : 1); ++side) {
+                    g.y_off = XP[s] + i + (side ? ushift : 0);
+                    g.x_off = XP[s] + i + ((lu && !side) ? ushift : 0);
+                    g.c_off = XP[a] + (side ? ushift : 0);
+                    g.strict = (lu && !side) ? 1 : 0;
+                    probs.push_back(g);
+                    add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                }
+                // executed flops of the tiles' useful part: Cholesky dn(dn+1)dk + 2 dm dn dk; LU twice minus the
+                // diagonal the L side skips (the reference's two GEMMs do 2(dn+dm)dn dk + 2 dm dn dk, L:2570-2577)
+                const double fl = lu ? (2.0 * (double)dnm * dn * nk + 2.0 * (double)(dnm - dn) * dn * nk)
+                                     : ((double)dn * (dn + 1) * nk + 2.0 * (double)(dnm - dn) * dn * nk);
                 p->flops_update += fl;
                 p->flops_exec += fl;
-                p->scatter_elems += (double)dn * (dn + 1) / 2.0 + (double)(dnm - dn) * dn;
+                p->scatter_elems += lu ? ((double)dnm * dn + (double)(dnm - dn) * dn)
+                                       : ((double)dn * (dn + 1) / 2.0 + (double)(dnm - dn) * dn);
                 p->n_pairs++;
                 i = e;
             }
@@ -334,6 +389,13 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
     for (sf_long k = 0; k < p->isize; ++k) Lsi32[k] = (int32_t)Lsi[k];
     std::vector<int64_t> Lp64(Lp, Lp + n + 1), Lsip64(Lsip, Lsip + nsuper + 1), Lsxp64(Lsxp, Lsxp + nsuper + 1);
     p->h_Lsip = Lsip64; p->h_Lsxp = Lsxp64; p->h_Super = Super32;
+    std::vector<int64_t> Up64;
+    std::vector<int32_t> Ui32;
+    if (lu && !p->u_alias) {
+        Up64.assign(Up, Up + n + 1);
+        Ui32.resize(p->unz);
+        for (sf_long k = 0; k < p->unz; ++k) Ui32[k] = (int32_t)Ui[k];
+    }
 
     int rc = SF_OK;
     do {
@@ -351,7 +413,17 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
         if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
-        const size_t xb = std::max<int64_t>(p->xsize, 1) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
+        if (lu) {
+            if ((rc = upload(&p->d_Xp, XP, &p->bytes_device))) break;
+            if (!p->u_alias) {
+                if ((rc = upload(&p->d_Up, Up64, &p->bytes_device))) break;
+                if ((rc = upload(&p->d_Ui, Ui32, &p->bytes_device))) break;
+                const size_t ub = std::max<int64_t>(p->unz, 1) * sizeof(double);
+                if (hipMalloc((void**)&p->d_Ux, ub) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+                p->bytes_device += ub;
+            }
+        }
+        const size_t xb = std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
             hipMalloc((void**)&p->d_info, sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
         p->bytes_device += xb + vb + sizeof(int);
@@ -361,10 +433,34 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
     return SF_OK;
 }
 
+int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
+                        const sf_long* Super, const sf_long* SuperMap,
+                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                        const sf_long* Lp, const sf_long* Li) {
+    return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr);
+}
+
+int sf_lu_plan_create(sf_lu_plan** out, int device, sf_long n, sf_long nsuper,
+                      const sf_long* Super, const sf_long* SuperMap,
+                      const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                      const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui) {
+    return plan_create(out, device, true, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui);
+}
+
 int sf_chol_plan_set_values(sf_chol_plan* p, const sf_float* Lx) {
-    if (!p || (!Lx && p->nnz > 0)) return SF_ERR_ARG;
+    if (!p || p->lu || (!Lx && p->nnz > 0)) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
     if (p->nnz > 0) HIP_TRY(hipMemcpyAsync(p->d_Lx, Lx, p->nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->values_set = true;
+    return SF_OK;
+}
+
+int sf_lu_plan_set_values(sf_lu_plan* p, const sf_float* Lx, const sf_float* Ux) {
+    if (!p || !p->lu || (!Lx && p->nnz > 0) || (!p->u_alias && !Ux && p->unz > 0)) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->nnz > 0) HIP_TRY(hipMemcpyAsync(p->d_Lx, Lx, p->nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    if (!p->u_alias && p->unz > 0) HIP_TRY(hipMemcpyAsync(p->d_Ux, Ux, p->unz * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->values_set = true;
     return SF_OK;
@@ -396,14 +492,30 @@ int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
 
     HIP_TRY(hipEventRecord(p->ev0, st));
     HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), st));
-    if (p->xsize > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, p->xsize * sizeof(double), st));
-    sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                           p->d_Lsi, p->d_Lsxp, p->d_Lsx, st);
+    if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
+    if (!p->lu) {
+        sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                               p->d_Lsi, p->d_Lsxp, p->d_Lsx, 0, st);
+    } else {
+        // L panel: strictly lower entries of the columns of L; U^T panel: row j of U (diagonal included) goes to
+        // column j of PU at the positions of its column indices (reference loadA, L:2490-2533)
+        sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                               p->d_Lsi, p->d_Xp, p->d_Lsx, 1, st);
+        if (p->u_alias)
+            sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                                   p->d_Lsi, p->d_Xp, p->d_Lsx + p->xC, 0, st);
+        else
+            sf::launch_load_panels(p->d_Up, p->d_Ui, p->d_Ux, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                                   p->d_Lsi, p->d_Xp, p->d_Lsx + p->xC, 0, st);
+    }
     mark();
     std::vector<int> kinds;
     for (const Launch& L : p->launches) {
         switch (L.kind) {
-            case 0: sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st); break;
+            case 0:
+                if (p->lu) sf::launch_getrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->xC, p->d_info, st);
+                else sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st);
+                break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
             case 2:
             case 4: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 0, p->d_Lsx, p->d_Lsi, st); break;
@@ -434,9 +546,29 @@ int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
     if (!p || (!Lsx && p->xsize > 0)) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (p->xsize > 0) HIP_TRY(hipMemcpy(Lsx, p->d_Lsx, p->xsize * sizeof(double), hipMemcpyDeviceToHost));
+    if (p->xsize <= 0) return SF_OK;
+    if (!p->lu) {
+        HIP_TRY(hipMemcpy(Lsx, p->d_Lsx, p->xsize * sizeof(double), hipMemcpyDeviceToHost));
+        return SF_OK;
+    }
+    if (!p->d_pack) {
+        HIP_TRY(hipMalloc((void**)&p->d_pack, p->xsize * sizeof(double)));
+        p->bytes_device += p->xsize * sizeof(double);
+    }
+    sf::launch_pack_lu(p->d_Super, p->d_Lsip, p->d_Xp, p->d_Lsxp, (int32_t)p->nsuper, p->d_Lsx, p->d_Lsx + p->xC,
+                       p->d_pack, p->xsize, p->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(Lsx, p->d_pack, p->xsize * sizeof(double), hipMemcpyDeviceToHost));
     return SF_OK;
 }
+
+int sf_lu_plan_factorize(sf_lu_plan* p, int sync) { return (p && p->lu) ? sf_chol_plan_factorize(p, sync) : SF_ERR_ARG; }
+int sf_lu_plan_sync(sf_lu_plan* p) { return sf_chol_plan_sync(p); }
+int sf_lu_plan_get_factor(sf_lu_plan* p, sf_float* Lsx) { return (p && p->lu) ? sf_chol_plan_get_factor(p, Lsx) : SF_ERR_ARG; }
+double sf_lu_plan_stat(const sf_lu_plan* p, const char* name) { return sf_chol_plan_stat(p, name); }
+int sf_lu_plan_set_profiling(sf_lu_plan* p, int on) { return sf_chol_plan_set_profiling(p, on); }
+int sf_lu_plan_destroy(sf_lu_plan* p) { return sf_chol_plan_destroy(p); }
 
 void* sf_chol_plan_factor_device_ptr(sf_chol_plan* p) { return p ? (void*)p->d_Lsx : nullptr; }
 

@@ -74,6 +74,18 @@ int sf_symbolic_create(sf_symbolic** out, sf_long n, const sf_long* Cp, const sf
     return SF_OK;
 }
 
+int sf_symbolic_create_lu(sf_symbolic** out, sf_long n, const sf_long* Cp, const sf_long* Ci, const sf_float* Cx,
+                          const sf_long* perm, size_t devSlotSize, int is_symmetric) {
+    if (!out) return SF_ERR_ARG;
+    *out = nullptr;
+    sf_symbolic* h = new (std::nothrow) sf_symbolic();
+    if (!h) return SF_ERR_ALLOC;
+    int rc = sf::analyze_lu(n, Cp, Ci, Cx, perm, devSlotSize, is_symmetric != 0, h->S);
+    if (rc) { delete h; return SF_ERR_ARG; }
+    *out = h;
+    return SF_OK;
+}
+
 void sf_symbolic_destroy(sf_symbolic* sym) { delete sym; }
 
 sf_long sf_symbolic_scalar(const sf_symbolic* sym, const char* name) {
@@ -89,6 +101,9 @@ sf_long sf_symbolic_scalar(const sf_symbolic* sym, const char* name) {
     if (k == "xsize") return S.xsize;
     if (k == "csize") return S.csize;
     if (k == "nsleaf") return S.nsleaf;
+    if (k == "lu") return S.lu ? 1 : 0;
+    if (k == "symmetric") return S.symmetric ? 1 : 0;
+    if (k == "unz") return S.Up.empty() ? 0 : S.Up[S.n];
     return -1;
 }
 
@@ -108,6 +123,10 @@ const sf_long* sf_symbolic_long_array(const sf_symbolic* sym, const char* name, 
     else if (k == "Li") v = &S.Li;
     else if (k == "LTp") v = &S.LTp;
     else if (k == "LTi") v = &S.LTi;
+    else if (k == "Up") v = &S.Up;
+    else if (k == "Ui") v = &S.Ui;
+    else if (k == "UTp") v = &S.UTp;
+    else if (k == "UTi") v = &S.UTi;
     else if (k == "Super") v = &S.Super;
     else if (k == "SuperMap") v = &S.SuperMap;
     else if (k == "Sparent") v = &S.Sparent;
@@ -132,6 +151,8 @@ const sf_float* sf_symbolic_float_array(const sf_symbolic* sym, const char* name
     const std::vector<double>* v = nullptr;
     if (k == "Lx") v = &sym->S.Lx;
     else if (k == "LTx") v = &sym->S.LTx;
+    else if (k == "Ux") v = &sym->S.Ux;
+    else if (k == "UTx") v = &sym->S.UTx;
     if (!v) return nullptr;
     if (len) *len = (sf_long)v->size();
     return v->data();

@@ -30,6 +30,7 @@ struct GemmProb {
     int32_t tgt_first_col;  // Super[a]
     int32_t tgt_nscol;
     int32_t tgt_nbelow;     // nsrow_a - nscol_a
+    int32_t strict;         // 1: only ci > cj is produced (LU: the L panel does not own the diagonal)
 };
 
 struct GemmTask {   // one 128x128 tile
@@ -44,16 +45,24 @@ struct PotrfTask {  // factor the b x b diagonal block at (diag, diag) of a pane
 };
 
 struct TrsmTask {   // rows [row0, row0+nrows) of panel columns [diag, diag+b) <- X * D^{-T}
-    int64_t panel;
+    int64_t panel;      // panel holding X
+    int64_t dpanel;     // panel holding the triangular block D at (diag, diag) (same ld); Cholesky: == panel
     int32_t ld, diag, b;
     int32_t row0, nrows;
-    int32_t pad;
+    int32_t unit;       // 1: D has an implicit unit diagonal (LU: U12^T <- U12^T * L11^{-T})
 };
 
+// skip_diag != 0: entries with row == column are not stored (LU: the L panel)
 void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
                         const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
-                        const int64_t* Lsxp, double* Lsx, hipStream_t st);
+                        const int64_t* Lsxp, double* Lsx, int skip_diag, hipStream_t st);
 void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st);
+// LU: the diagonal block is split over two panels, L (strictly lower, at Lsx + task.panel) and U^T (lower
+// including the diagonal, at Lsx + task.panel + u_shift)
+void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, hipStream_t st);
+// LU: gather the (L, U^T) panel pairs into the reference's (2*nsrow - nscol) x nscol panels (LU/Source/SparseFrame.c:2514-2517)
+void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
+                    const double* PL, const double* PU, double* out, int64_t ref_size, hipStream_t st);
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
 // kt_prefix[0..ntasks]: running count of 16-deep K steps of the launch's tiles (kt_prefix[ntasks] = total_units)
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256)
 k_load_panels(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, const double* __restrict__ Lx, int32_t n,
               const int32_t* __restrict__ Super, const int32_t* __restrict__ SuperMap,
               const int64_t* __restrict__ Lsip, const int32_t* __restrict__ Lsi,
-              const int64_t* __restrict__ Lsxp, double* __restrict__ Lsx) {
+              const int64_t* __restrict__ Lsxp, double* __restrict__ Lsx, int skip_diag) {
     const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int32_t s = SuperMap[j];
@@ -49,6 +49,7 @@ k_load_panels(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, co
     const int32_t* below = Lsi + r0 + nscol;
     for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) {
         const int32_t i = Li[p];
+        if (skip_diag && i == j) continue;
         const int32_t si = (i < c1) ? (i - c0) : nscol + lower_bound_i32(below, nsrow - nscol, i);
         col[si] = Lx[p];
     }
@@ -56,10 +57,10 @@ k_load_panels(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, co
 
 void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
                         const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
-                        const int64_t* Lsxp, double* Lsx, hipStream_t st) {
+                        const int64_t* Lsxp, double* Lsx, int skip_diag, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_load_panels, dim3((n + 255) / 256), dim3(256), 0, st,
-                       Lp, Li, Lx, n, Super, SuperMap, Lsip, Lsi, Lsxp, Lsx);
+                       Lp, Li, Lx, n, Super, SuperMap, Lsip, Lsi, Lsxp, Lsx, skip_diag);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -114,6 +115,88 @@ void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hi
 }
 
 // ---------------------------------------------------------------------------------------------------
+// No-pivot LU of a b x b (b <= 64) diagonal block (reference: magma_dgetrf_nopiv, LU/Source/SparseFrame.c:2653,
+// cusolverDnDgetrf with devIpiv = NULL, :3344).  Same one-wavefront scheme as k_potrf_block: lane r holds row r
+// of the block, a[c] = D(r,c); at step j lane j's row is broadcast with v_readlane.  The block lives in two
+// panels: D(r,c), c < r (L, unit diagonal implied) in the L panel at (diag+r, diag+c); D(r,c), c >= r (U) in
+// the U^T panel at (diag+c, diag+r).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int64_t u_shift, int* __restrict__ info) {
+    const PotrfTask t = tasks[blockIdx.x];
+    double* PLd = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
+    double* PUd = PLd + u_shift;
+    const int b = t.b;
+    const int lane = threadIdx.x;
+    const int64_t ld = t.ld;
+
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        double v = (c == lane) ? 1.0 : 0.0;
+        if (lane < b && c < b) v = (c < lane) ? PLd[lane + c * ld] : PUd[c + lane * ld];
+        a[c] = v;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double piv = readlane_f64(a[j], j);
+        bad = bad || !(piv != 0.0);         // zero or NaN pivot; padded rows have piv = 1
+        const double l = (lane > j) ? a[j] / piv : 0.0;
+        if (lane > j) a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_f64(a[c], j);
+    }
+    if (bad && lane == 0) atomicExch(info, 1);
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        if (lane < b && c < b) {
+            if (c < lane) PLd[lane + c * ld] = a[c]; else PUd[c + lane * ld] = a[c];
+        }
+    }
+}
+
+void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, hipStream_t st) {
+    if (ntasks <= 0) return;
+    hipLaunchKernelGGL(k_getrf_block, dim3(ntasks), dim3(64), 0, st, tasks, Lsx, u_shift, info);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LU download: thread per value of the reference layout; supernode found by binary search in RefXp.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pack_lu(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsip, const int64_t* __restrict__ Xp,
+          const int64_t* __restrict__ RefXp, int32_t nsuper, const double* __restrict__ PL, const double* __restrict__ PU,
+          double* __restrict__ out, int64_t ref_size) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ref_size; e += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nsuper;            // largest s with RefXp[s] <= e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (RefXp[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int s = lo;
+        const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        const int64_t lda = 2 * nsrow - nscol;
+        const int64_t off = e - RefXp[s];
+        const int64_t j = off / lda, R = off % lda;
+        const double* pl = PL + Xp[s] + j * nsrow;       // column j of the L panel
+        double v;
+        if (R < nscol) v = (R > j) ? pl[R] : PU[Xp[s] + j + R * nsrow];          // packed L11 \ U11: U(R,j) = PU(j,R)
+        else if (R < nsrow) v = pl[R];                                             // L21
+        else v = PU[Xp[s] + (R - nsrow + nscol) + j * nsrow];                      // U12^T
+        out[e] = v;
+    }
+}
+
+void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
+                    const double* PL, const double* PU, double* out, int64_t ref_size, hipStream_t st) {
+    if (ref_size <= 0) return;
+    const int64_t blocks = (ref_size + 255) / 256;
+    hipLaunchKernelGGL(k_pack_lu, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
+                       Super, Lsip, Xp, RefXp, nsuper, PL, PU, out, ref_size);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // X <- X * D^{-T} for a tile of rows, D = lower-triangular b x b block already factored.
 // One row per lane (rows are contiguous in memory: coalesced 8-byte accesses per column).
 // The row is solved 8 columns at a time: the 8 running sums live in registers, the contributions of
@@ -125,7 +208,7 @@ k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx) {
     __shared__ __attribute__((aligned(16))) double Dt[NB][NB];   // Dt[k][j] = L(j,k) for k < j, else 0
     __shared__ double Dinv[NB];
     const TrsmTask t = tasks[blockIdx.x];
-    const double* Dg = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
+    const double* Dg = Lsx + t.dpanel + t.diag + (int64_t)t.diag * t.ld;
     const int b = t.b;
     const int tid = threadIdx.x;
 
@@ -133,7 +216,7 @@ k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx) {
         const int k = e / NB, j = e % NB;   // column k, row j of the block: coalesced along j
         Dt[k][j] = (j < b && k < j) ? Dg[j + (int64_t)k * t.ld] : 0.0;
     }
-    if (tid < NB) Dinv[tid] = (tid < b) ? 1.0 / Dg[tid + (int64_t)tid * t.ld] : 1.0;
+    if (tid < NB) Dinv[tid] = (tid < b && !t.unit) ? 1.0 / Dg[tid + (int64_t)tid * t.ld] : 1.0;
     __syncthreads();
 
     if (tid >= t.nrows) return;
@@ -348,7 +431,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                     for (int r = 0; r < 4; ++r) {
                         const int lcj = wn * 64 + tm * 16 + fk + 4 * r;
                         const int cj = cj0 + lcj;
-                        if (ci < M && cj < N && ci >= cj) {
+                        if (ci < M && cj < N && ci >= cj + pb.strict) {
                             const double v = acc[tm][tn][r];
                             if (MODE == 1) {
                                 unsafeAtomicAdd(Cg + rowmap[lci] + (int64_t)colmap[lcj] * ldc, -v);

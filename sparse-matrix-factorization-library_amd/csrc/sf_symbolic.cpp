@@ -31,8 +31,50 @@ bool relax_allowed(Long ncol, double zero_rate) {
 
 // lower(P A P^T) by column (column = min(i,j), row = max(i,j)) and its transpose.
 // Entry order inside a column follows the traversal order of C:1036-1063.
+// LU with an unsymmetric input (L:1179-1282): entry (i,j) of P A P^T goes to L (by column j, rows i >= j) when
+// j <= i and to U (by ROW i, columns j >= i) when j >= i; the diagonal is in both.
+void build_lu_parts(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+                    const std::vector<Long>& Perm, Symbolic& S) {
+    std::vector<Long> Pinv(n, -1);
+    for (Long j = 0; j < n; ++j)
+        if (Perm[j] >= 0) Pinv[Perm[j]] = j;
+    S.Lp.assign(n + 1, 0); S.LTp.assign(n + 1, 0); S.Up.assign(n + 1, 0); S.UTp.assign(n + 1, 0);
+    for (Long j = 0; j < n; ++j) {
+        const Long jold = Perm[j];
+        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
+            const Long i = Pinv[Ci[p]];
+            if (j <= i) { S.Lp[j + 1]++; S.LTp[i + 1]++; }
+            if (j >= i) { S.Up[i + 1]++; S.UTp[j + 1]++; }
+        }
+    }
+    for (Long j = 0; j < n; ++j) {
+        S.Lp[j + 1] += S.Lp[j]; S.LTp[j + 1] += S.LTp[j];
+        S.Up[j + 1] += S.Up[j]; S.UTp[j + 1] += S.UTp[j];
+    }
+    S.Li.resize(S.Lp[n]); S.Lx.resize(S.Lp[n]); S.LTi.resize(S.Lp[n]); S.LTx.resize(S.Lp[n]);
+    S.Ui.resize(S.Up[n]); S.Ux.resize(S.Up[n]); S.UTi.resize(S.Up[n]); S.UTx.resize(S.Up[n]);
+    std::vector<Long> ln(S.Lp.begin(), S.Lp.end() - 1), ltn(S.LTp.begin(), S.LTp.end() - 1);
+    std::vector<Long> un(S.Up.begin(), S.Up.end() - 1), utn(S.UTp.begin(), S.UTp.end() - 1);
+    for (Long j = 0; j < n; ++j) {
+        const Long jold = Perm[j];
+        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
+            const Long i = Pinv[Ci[p]];
+            const double v = Cx ? Cx[p] : 0.0;
+            if (j <= i) {
+                const Long lp = ln[j]++;  S.Li[lp] = i;  S.Lx[lp] = v;
+                const Long tp = ltn[i]++; S.LTi[tp] = j; S.LTx[tp] = v;
+            }
+            if (j >= i) {
+                const Long up = un[i]++;  S.Ui[up] = j;  S.Ux[up] = v;
+                const Long tp = utn[j]++; S.UTi[tp] = i; S.UTx[tp] = v;
+            }
+        }
+    }
+}
+
 void build_triangles(Long n, const Long* Cp, const Long* Ci, const double* Cx,
                      const std::vector<Long>& Perm, Symbolic& S) {
+    if (S.lu && !S.symmetric) { build_lu_parts(n, Cp, Ci, Cx, Perm, S); return; }
     std::vector<Long> Pinv(n, -1);
     for (Long j = 0; j < n; ++j)
         if (Perm[j] >= 0) Pinv[Perm[j]] = j;
@@ -78,17 +120,20 @@ void elimination_tree(const Symbolic& S, std::vector<Long>& Parent) {
     const Long n = S.n;
     Parent.assign(n, -1);
     std::vector<Long> Anc(n, -1);
-    for (Long j = 0; j < n; ++j) {
-        for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) {
-            Long i = S.LTi[p];
-            while (i >= 0 && i < j) {
-                const Long a = Anc[i];
-                Anc[i] = j;
-                if (a < 0) { Parent[i] = j; break; }
-                if (a == j) break;
-                i = a;
-            }
+    auto climb = [&](Long i, Long j) {
+        while (i >= 0 && i < j) {
+            const Long a = Anc[i];
+            Anc[i] = j;
+            if (a < 0) { Parent[i] = j; break; }
+            if (a == j) break;
+            i = a;
         }
+    };
+    const bool both = S.lu && !S.symmetric;     // LU: tree of the pattern of L + U^T (L:1358-1383)
+    for (Long j = 0; j < n; ++j) {
+        for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) climb(S.LTi[p], j);
+        if (both)
+            for (Long p = S.UTp[j]; p < S.UTp[j + 1]; ++p) climb(S.UTi[p], j);
     }
 }
 
@@ -153,12 +198,12 @@ void column_counts(const Symbolic& S, const std::vector<Long>& Parent, const std
         for (Long p = Post[k]; p >= 0 && First[p] < 0; p = Parent[p]) First[p] = k;
     }
     for (Long j = 0; j < n; ++j) { Set[j] = j; PrevLeaf[j] = j; }
+    const bool both = S.lu && !S.symmetric;     // LU: counts of the pattern of L + U^T (L:1601-1625)
     for (Long k = 0; k < n; ++k) {
         const Long j = Post[k];
         PrevNbr[j] = k;
-        for (Long p = S.Lp[j]; p < S.Lp[j + 1]; ++p) {
-            const Long i = S.Li[p];
-            if (i <= j) continue;
+        auto visit = [&](Long i) {
+            if (i <= j) return;
             if (First[j] > PrevNbr[i]) {
                 const Long pl = PrevLeaf[i];
                 Long r = pl;
@@ -169,7 +214,10 @@ void column_counts(const Symbolic& S, const std::vector<Long>& Parent, const std
                 PrevLeaf[i] = j;
             }
             PrevNbr[i] = k;
-        }
+        };
+        for (Long p = S.Lp[j]; p < S.Lp[j + 1]; ++p) visit(S.Li[p]);
+        if (both)
+            for (Long p = S.Up[j]; p < S.Up[j + 1]; ++p) visit(S.Ui[p]);
         Set[j] = Parent[j];
     }
     for (Long k = 0; k < n; ++k) {
@@ -179,19 +227,38 @@ void column_counts(const Symbolic& S, const std::vector<Long>& Parent, const std
     for (Long j = 0; j < n; ++j) Count[j]++;
 }
 
-inline bool fits_slot(Long ncol, Long nrow, size_t slot) {
-    // (ncol*nrow)*sizeof(Float) + nrow*sizeof(Long) <= devSlotSize, in size_t arithmetic (C:1482-1484)
-    return (size_t)ncol * (size_t)nrow * sizeof(double) + (size_t)nrow * sizeof(Long) <= slot;
+// number of values of a panel with ncol columns and nrow rows in its row list:
+// Cholesky nrow*ncol (C:1641), LU (2*nrow - ncol)*ncol (L:1946)
+inline Long panel_values(bool lu, Long ncol, Long nrow) { return lu ? ncol * (2 * nrow - ncol) : ncol * nrow; }
+
+inline bool fits_slot(bool lu, Long ncol, Long nrow, size_t slot) {
+    // panel values * sizeof(Float) + nrow * sizeof(Long) <= devSlotSize, in size_t arithmetic (C:1482-1484, L:1787-1789)
+    return (size_t)panel_values(lu, ncol, nrow) * sizeof(double) + (size_t)nrow * sizeof(Long) <= slot;
 }
 
 }  // namespace
 
+static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+                       const Long* perm, size_t devSlotSize, bool lu, bool symmetric, Symbolic& S);
+
 int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
                      const Long* perm, size_t devSlotSize, Symbolic& S) {
+    return analyze_any(n, Cp, Ci, Cx, perm, devSlotSize, false, true, S);
+}
+
+int analyze_lu(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+               const Long* perm, size_t devSlotSize, bool symmetric, Symbolic& S) {
+    return analyze_any(n, Cp, Ci, Cx, perm, devSlotSize, true, symmetric, S);
+}
+
+static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+                       const Long* perm, size_t devSlotSize, bool lu, bool symmetric, Symbolic& S) {
     if (n < 0 || !Cp || (n > 0 && !Ci)) return 1;
     S = Symbolic();
     S.n = n;
     S.devSlotSize = devSlotSize;
+    S.lu = lu;
+    S.symmetric = symmetric;
 
     std::vector<Long> Perm(n);
     for (Long j = 0; j < n; ++j) Perm[j] = perm ? perm[j] : j;
@@ -242,7 +309,7 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     for (Long j = 1; j < n; ++j) {
         const Long first = Fsuper.back();
         const bool chain_breaks = (Par[j - 1] != j) || (CC[j - 1] != CC[j] + 1) || (Nchild[j] > 1);
-        if (chain_breaks || !fits_slot(j - first + 1, CC[first], devSlotSize)) Fsuper.push_back(j);
+        if (chain_breaks || !fits_slot(lu, j - first + 1, CC[first], devSlotSize)) Fsuper.push_back(j);
     }
     const Long nf = (Long)Fsuper.size();
     Fsuper.push_back(n);
@@ -267,7 +334,7 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
         if (sp < 0 || sp >= nf || Merge[s + 1] != Merge[sp]) continue;
         const Long g = Merge[sp];
         const Long s_n = Nscol[s], p_n = Nscol[g], s_c = Scc[s], p_c = Scc[g];
-        if (!fits_slot(s_n + p_n, s_n + p_c, devSlotSize)) continue;
+        if (!fits_slot(lu, s_n + p_n, s_n + p_c, devSlotSize)) continue;
         const Long total_zero = Nsz[s] + Nsz[g] + s_n * (s_n + p_c - s_c);
         const Long tot = s_n + p_n;
         const Long denom = tot * (tot + 1) / 2 + tot * (p_c - p_n);
@@ -310,7 +377,7 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     S.Lsxp.assign(ns + 1, 0);
     for (Long s = 0; s < ns; ++s) {
         S.Lsip[s + 1] = S.Lsip[s] + Gcc[s];
-        S.Lsxp[s + 1] = S.Lsxp[s] + Gncol[s] * Gcc[s];
+        S.Lsxp[s + 1] = S.Lsxp[s] + panel_values(lu, Gncol[s], Gcc[s]);
     }
     S.isize = S.Lsip[ns];
     S.xsize = S.Lsxp[ns];
@@ -324,12 +391,17 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
             Marker[s] = S.Super[s + 1];
             for (Long k = S.Super[s]; k < S.Super[s + 1]; ++k) S.Lsi[fill[s]++] = k;
         }
+        const bool both = lu && !symmetric;
         for (Long j = 0; j < n; ++j) {
-            for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) {
-                for (Long d = S.SuperMap[S.LTi[p]]; d >= 0 && Marker[d] <= j; d = S.Sparent[d]) {
-                    if (fill[d] >= S.Lsip[d + 1]) return 2;  // count mismatch: symbolic inconsistency
-                    S.Lsi[fill[d]++] = j;
-                    Marker[d] = j + 1;
+            for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
+                const std::vector<Long>& Tp = pass ? S.UTp : S.LTp;
+                const std::vector<Long>& Ti = pass ? S.UTi : S.LTi;
+                for (Long p = Tp[j]; p < Tp[j + 1]; ++p) {
+                    for (Long d = S.SuperMap[Ti[p]]; d >= 0 && Marker[d] <= j; d = S.Sparent[d]) {
+                        if (fill[d] >= S.Lsip[d + 1]) return 2;  // count mismatch: symbolic inconsistency
+                        S.Lsi[fill[d]++] = j;
+                        Marker[d] = j + 1;
+                    }
                 }
             }
         }
@@ -349,7 +421,8 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
         for (Long si = nscol; si < nsrow; ++si) {
             const Long o = S.SuperMap[rows[si]];
             if (o != owner) {
-                S.csize = std::max(S.csize, (si - start) * (nsrow - start));
+                // Cholesky (si-start)*(nsrow-start) (C:1711); LU adds the U^T rows: (si-start)*(2*nsrow-si-start) (L:2028)
+                S.csize = std::max(S.csize, (si - start) * (lu ? (2 * nsrow - si - start) : (nsrow - start)));
                 start = si;
                 owner = o;
             }
@@ -367,7 +440,7 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
             return (size_t)(Asz[st] + a) * sizeof(double) + (size_t)(Msz[st] + m) * sizeof(Long) <= devSlotSize;
         };
         for (Long s = ns - 1; s >= 0; --s) {
-            const Long a = (S.Super[s + 1] - S.Super[s]) * (S.Lsip[s + 1] - S.Lsip[s]);
+            const Long a = panel_values(lu, S.Super[s + 1] - S.Super[s], S.Lsip[s + 1] - S.Lsip[s]);
             const Long m = S.Lsip[s + 1] - S.Lsip[s];
             Long st;
             const Long sp = S.Sparent[s];
@@ -438,7 +511,7 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
             const Long nscol = S.Super[s + 1] - S.Super[s];
             const Long nsrow = S.Lsip[s + 1] - S.Lsip[s];
             S.Aoffset[s] = (Long)asz;
-            asz += (size_t)(nscol * nsrow) * sizeof(double);
+            asz += (size_t)panel_values(lu, nscol, nsrow) * sizeof(double);
             S.Moffset[s] = (Long)msz;
             msz += (size_t)nsrow * sizeof(Long);
         }
@@ -449,7 +522,9 @@ int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
 
 double flops_struct(const Symbolic& S) {
     double f = 0;
-    for (Long c : S.ColCount0) f += (double)c * (double)c;
+    // Cholesky: sum c^2 ; no-pivot LU on the symmetrised pattern: sum (c-1) + 2 (c-1)^2   
+    for (Long c : S.ColCount0)
+        f += S.lu ? ((double)(c - 1) + 2.0 * (double)(c - 1) * (double)(c - 1)) : (double)c * (double)c;
     return f;
 }
 
@@ -459,7 +534,8 @@ double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems
         const double n = (double)(S.Super[s + 1] - S.Super[s]);
         const Long nsrow = S.Lsip[s + 1] - S.Lsip[s];
         const double m = (double)nsrow - n;
-        fac += n * n * n / 3.0 + m * n * n;
+        // Cholesky n^3/3 + m n^2 ; LU r n^2 - n^3/3 + m n^2 with r = nsrow
+        fac += S.lu ? ((double)nsrow * n * n - n * n * n / 3.0 + m * n * n) : (n * n * n / 3.0 + m * n * n);
         const Long* rows = &S.Lsi[S.Lsip[s]];
         Long i = (Long)n;
         while (i < nsrow) {
@@ -467,8 +543,9 @@ double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems
             Long e = i;
             while (e < nsrow && S.SuperMap[rows[e]] == owner) ++e;
             const double dn = (double)(e - i), dm = (double)(nsrow - e);
-            upd += dn * (dn + 1) * n + 2.0 * dm * dn * n;
-            sc += dn * (dn + 1) / 2.0 + dm * dn;
+            // LU: two GEMMs per update, (dn+dm) x dn x dk and dm x dn x dk (L:2570-2577)
+            upd += S.lu ? (2.0 * (dn + dm) * dn * n + 2.0 * dm * dn * n) : (dn * (dn + 1) * n + 2.0 * dm * dn * n);
+            sc += S.lu ? ((dn + dm) * dn + dm * dn) : (dn * (dn + 1) / 2.0 + dm * dn);
             i = e;
         }
     }

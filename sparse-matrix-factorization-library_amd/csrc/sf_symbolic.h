@@ -12,9 +12,15 @@ struct Symbolic {
     Long n = 0;
     size_t devSlotSize = 0;
 
+    bool lu = false;         // LU path (reference LU/Source/SparseFrame.c): panels are (2*nsrow - nscol) x nscol
+    bool symmetric = true;   // input holds one triangle of a symmetric matrix (LU: U aliases L, L:2718-2729)
+
     // permuted lower triangle (by column) and its transpose; reference C:956-1066
     std::vector<Long> Lp, Li, LTp, LTi;
     std::vector<double> Lx, LTx;
+    // LU, unsymmetric input only: U by ROW (Up[i]..: column indices j >= i) and its transpose (L:1179-1282)
+    std::vector<Long> Up, Ui, UTp, UTi;
+    std::vector<double> Ux, UTx;
 
     std::vector<Long> Perm;      // final (post-order composed), C:1438
     std::vector<Long> Parent;    // final numbering, C:1439
@@ -40,6 +46,10 @@ struct Symbolic {
 // Returns 0 on success.
 int analyze_cholesky(Long n, const Long* Cp, const Long* Ci, const double* Cx,
                      const Long* perm, size_t devSlotSize, Symbolic& out);
+// LU variant (reference LU/Source/SparseFrame.c:1068-2231).  symmetric != 0: Cp/Ci/Cx hold one triangle;
+// otherwise the whole (structurally unsymmetric) matrix in CSC.
+int analyze_lu(Long n, const Long* Cp, const Long* Ci, const double* Cx,
+               const Long* perm, size_t devSlotSize, bool symmetric, Symbolic& out);
 
 // flop counters
 double flops_struct(const Symbolic& S);

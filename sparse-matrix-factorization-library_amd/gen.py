@@ -115,6 +115,56 @@ def arrow_spd_lower(n, width=1):
     return n, Cp, Ci, Cx
 
 
+def unsymmetric_stencil(nx, ny=1, nz=1, extra_per_row=1, seed=2024, reach=1):
+    """BASELINE config 5 generator: 3-D stencil of faces + edges within `reach` (19-point for
+    reach=1), plus `extra_per_row` random off-pattern entries per row (structurally unsymmetric), independent
+    values U(-1,-0.5) for (i,j) and (j,i), diagonal 1 + sum of |row| + |column| so that NO-PIVOT LU is stable
+    (the reference never pivots).  Returns the whole matrix in CSC (n, Cp, Ci, Cx)."""
+    n = nx * ny * nz
+    rng = np.random.default_rng(seed)
+    idx = np.arange(n, dtype=np.int64)
+    x = idx % nx
+    y = (idx // nx) % ny
+    z = idx // (nx * ny)
+    rows, cols = [], []
+    for dz in range(-reach, reach + 1):
+        for dy in range(-reach, reach + 1):
+            for dx in range(-reach, reach + 1):
+                if (dx, dy, dz) == (0, 0, 0) or abs(dx) + abs(dy) + abs(dz) > 2 * reach:
+                    continue
+                if nz == 1 and dz or ny == 1 and dy:
+                    continue
+                m = (x + dx >= 0) & (x + dx < nx) & (y + dy >= 0) & (y + dy < ny) & (z + dz >= 0) & (z + dz < nz)
+                j = idx[m]
+                rows.append(j + dx + dy * nx + dz * nx * ny)
+                cols.append(j)
+    if extra_per_row:
+        r = np.repeat(idx, extra_per_row)
+        c = rng.integers(0, n, size=r.size)
+        keep = r != c
+        rows.append(r[keep])
+        cols.append(c[keep])
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    key = np.unique(cols * n + rows)
+    cols, rows = key // n, key % n
+    vals = rng.uniform(-1.0, -0.5, size=rows.size)
+    d = np.ones(n)
+    np.add.at(d, rows, np.abs(vals))
+    np.add.at(d, cols, np.abs(vals))
+    rows = np.concatenate([rows, idx])
+    cols = np.concatenate([cols, idx])
+    vals = np.concatenate([vals, d])
+    Cp, Ci, Cx = _csc_from_coo(n, rows, cols, vals)
+    return n, Cp, Ci, Cx
+
+
+def dense_from_csc(n, Cp, Ci, Cx):
+    A = np.zeros((n, n))
+    for j in range(n):
+        A[Ci[Cp[j]:Cp[j + 1]], j] = Cx[Cp[j]:Cp[j + 1]]
+    return A
+
+
 def dense_from_lower(n, Cp, Ci, Cx):
     """dense symmetric matrix from a stored triangle (small n only)."""
     A = np.zeros((n, n))

@@ -1,0 +1,134 @@
+"""No-pivot supernodal LU (SURVEY 8a row a-LU).  CPU part: product analysis vs the oracle's restatement (bit-exact),
+oracle numeric vs dense no-pivot LU (the factors are unique).  GPU part: HIP path vs the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from util import sf, gen, nd_perm_py, INT_ARRAYS, INT_SCALARS, rel_err
+
+TOL_FACTOR = 1e-12
+TOL_RESIDUAL = 1e-13
+
+
+def lu_cases():
+    c = []
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(6, 6, 1, seed=1)
+    c.append(("st2d_6x6_id", n, Cp, Ci, Cx, None, 1 << 30, False))
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(12, 9, 1, seed=2)
+    c.append(("st2d_12x9_nd", n, Cp, Ci, Cx, nd_perm_py(12, 9, 1), 1 << 30, False))
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(5, 5, 5, seed=3)
+    c.append(("st3d_5_nd", n, Cp, Ci, Cx, nd_perm_py(5, 5, 5), 1 << 30, False))
+    c.append(("st3d_5_nd_smallslot", n, Cp, Ci, Cx, nd_perm_py(5, 5, 5), 9000, False))
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(8, 8, 8, seed=4)
+    c.append(("st3d_8_nd", n, Cp, Ci, Cx, nd_perm_py(8, 8, 8), 1 << 30, False))
+    n, Cp, Ci, Cx = gen.laplacian_lower(7, 7, 7)
+    c.append(("sym_lap3d_7_via_lu", n, Cp, Ci, Cx, nd_perm_py(7, 7, 7), 1 << 30, True))
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(40, 1, 1, extra_per_row=3, seed=5)
+    c.append(("rand_40", n, Cp, Ci, Cx, None, 1 << 30, False))
+    c.append(("one_by_one", 1, np.array([0, 1]), np.array([0]), np.array([3.0]), None, 1 << 30, False))
+    return c
+
+
+def dense_lu_nopiv(A):
+    A = A.copy()
+    for k in range(len(A)):
+        A[k + 1:, k] /= A[k, k]
+        A[k + 1:, k + 1:] -= np.outer(A[k + 1:, k], A[k, k + 1:])
+    return A
+
+
+def reference_layout_from_dense(S, LU):
+    out = np.zeros(S.xsize)
+    for s in range(S.nsuper):
+        c0, c1 = S.Super[s], S.Super[s + 1]
+        nscol = c1 - c0
+        rows = S.Lsi[S.Lsip[s]:S.Lsip[s + 1]]
+        nsrow = len(rows)
+        lda = 2 * nsrow - nscol
+        P = np.zeros((lda, nscol))
+        P[:nsrow, :] = LU[np.ix_(rows, range(c0, c1))]
+        if nsrow > nscol:
+            P[nsrow:, :] = LU[np.ix_(range(c0, c1), rows[nscol:])].T
+        out[S.Lsxp[s]:S.Lsxp[s + 1]] = P.T.ravel()
+    return out
+
+
+@pytest.mark.parametrize("case", lu_cases(), ids=lambda c: c[0])
+def test_lu_symbolic_bit_exact(oracle, case):
+    name, n, Cp, Ci, Cx, perm, slot, symm = case
+    P = sf.analyze(n, Cp, Ci, Cx, perm, slot, "lu", symm)
+    O = oracle.symbolic.analyze(n, Cp, Ci, Cx, perm, slot, lu=True, symmetric=symm)
+    for k in INT_SCALARS + ("unz",):
+        assert getattr(P, k) == O[k], k
+    for k in INT_ARRAYS + ("Up", "Ui", "UTp", "UTi"):
+        assert np.array_equal(getattr(P, k), np.asarray(O[k], dtype=np.int64)), k
+    assert np.array_equal(P.Lx, np.asarray(O["Lx"])) and np.array_equal(P.Ux, np.asarray(O["Ux"]))
+
+
+@pytest.mark.parametrize("blas", ["builtin", "auto"])
+@pytest.mark.parametrize("case", lu_cases(), ids=lambda c: c[0])
+def test_lu_oracle_against_dense(oracle, case, blas):
+    name, n, Cp, Ci, Cx, perm, slot, symm = case
+    oracle.blas_init(blas, threads=2)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, slot, "lu", symm)
+    Lsx, info, st = oracle.lu_factorize(S)
+    assert info == 0
+    A = gen.dense_from_lower(n, Cp, Ci, Cx) if symm else gen.dense_from_csc(n, Cp, Ci, Cx)
+    Ap = A[np.ix_(S.Perm, S.Perm)]
+    want = reference_layout_from_dense(S, dense_lu_nopiv(Ap))
+    assert rel_err(Lsx, want) <= TOL_FACTOR
+    res, x = oracle.lu_residual(S, Lsx)
+    assert res <= TOL_RESIDUAL
+    b = 1 + np.arange(n) / n
+    assert np.allclose(Ap @ x, b, rtol=0, atol=1e-9 * np.abs(b).max())
+    assert abs(st["flops_gemm"] + st["flops_getrf"] + st["flops_trsm"] - S.flops_exec) <= 1e-9 * max(S.flops_exec, 1)
+    oracle.blas_init("auto", threads=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", lu_cases(), ids=lambda c: c[0])
+def test_lu_gpu_matches_oracle(oracle, case):
+    name, n, Cp, Ci, Cx, perm, slot, symm = case
+    S = sf.analyze(n, Cp, Ci, Cx, perm, slot, "lu", symm)
+    plan = sf.LUPlan(S)
+    plan.set_values(S.Lx, None if symm else S.Ux)
+    plan.factorize()
+    Lsx = plan.get_factor()
+    ref, info, _ = oracle.lu_factorize(S)
+    assert info == 0
+    assert rel_err(Lsx, ref) <= TOL_FACTOR
+    res, _ = oracle.lu_residual(S, Lsx)
+    assert res <= TOL_RESIDUAL
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [20, 32])
+def test_lu_gpu_medium(oracle, N):
+    """supernodes of several hundred columns: blocked panels, outer/inner updates, multi-tile Schur updates"""
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=7)
+    S = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), sf.REFERENCE_SLOT_1GPU, "lu", False)
+    plan = sf.LUPlan(S)
+    plan.set_values(S.Lx, S.Ux)
+    plan.factorize()
+    Lsx = plan.get_factor()
+    ref, info, _ = oracle.lu_factorize(S)
+    assert info == 0
+    assert rel_err(Lsx, ref) <= TOL_FACTOR
+    res, _ = oracle.lu_residual(S, Lsx)
+    assert res <= TOL_RESIDUAL
+    assert abs(plan.stat("flops_exec") - S.flops_exec) <= 1e-9 * S.flops_exec
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_lu_zero_pivot_is_reported():
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(5, 5, 1, seed=9)
+    Cx = Cx.copy()
+    d = [p for j in range(n) for p in range(Cp[j], Cp[j + 1]) if Ci[p] == j]
+    Cx[d[0]] = 0.0
+    S = sf.analyze(n, Cp, Ci, Cx, None, 1 << 30, "lu", False)
+    plan = sf.LUPlan(S)
+    plan.set_values(S.Lx, S.Ux)
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_NOT_POSDEF"):
+        plan.factorize()
+    plan.close()
