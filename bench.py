@@ -34,7 +34,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=128, help="N of the N^3 Laplacian (128 = BASELINE config 2)")
+    ap.add_argument("--grid", type=int, default=0, help="N of the N^3 grid (default: 128 for cholesky = BASELINE config 2, 79 for lu = config 5)")
+    ap.add_argument("--method", choices=["cholesky", "lu"], default="cholesky",
+                    help="cholesky: 3-D 7-pt Laplacian (the headline workload); lu: unsymmetric 19-pt stencil, no-pivot LU")
     ap.add_argument("--cpu-grid", type=int, default=72, help="N of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="BLAS threads of the CPU baseline (0 = min(cores,16))")
     ap.add_argument("--check", action="store_true", help="download the factor and check the residual on the host")
@@ -60,17 +62,28 @@ def main():
     if sf.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the numeric path has no CPU fallback")
 
-    N = args.grid
+    lu = args.method == "lu"
+    N = args.grid or (79 if lu else 128)
     t0 = time.time()
-    n, Cp, Ci, Cx = sf.gen.laplacian_lower(N, N, N)
-    perm = sf.grid_nd_perm(N, N, N, 3, 1)
-    sym = sf.analyze(n, Cp, Ci, Cx, perm, sf.REFERENCE_SLOT_1GPU)
+
+    def make(M):
+        if lu:   # BASELINE config 5 stand-in: n ~ 500k, nnz ~ 9M, structurally and numerically unsymmetric, diagonally dominant
+            n_, Cp_, Ci_, Cx_ = sf.gen.unsymmetric_stencil(M, M, M, extra_per_row=0, seed=2024, drop=0.05)
+            return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False), len(Ci_)
+        n_, Cp_, Ci_, Cx_ = sf.gen.laplacian_lower(M, M, M)
+        return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU), len(Ci_)
+
+    n, sym, nnz_in = make(N)
     t_analyze = time.time() - t0
     F_struct, F_exec = sym.flops_struct, sym.flops_exec
 
     t0 = time.time()
-    plan = sf.CholPlan(sym, device=local_rank)
-    plan.set_values(sym.Lx)
+    if lu:
+        plan = sf.LUPlan(sym, device=local_rank)
+        plan.set_values(sym.Lx, sym.Ux)
+    else:
+        plan = sf.CholPlan(sym, device=local_rank)
+        plan.set_values(sym.Lx)
     t_plan = time.time() - t0
 
     def barrier():
@@ -96,12 +109,14 @@ def main():
     value = F_struct * ngpu / (elapsed / args.steps) / 1e9
 
     out = {
-        "metric": "numeric-factorization GFLOP/s (supernodal Cholesky)",
+        "metric": "numeric-factorization GFLOP/s (supernodal %s)" % ("no-pivot LU" if lu else "Cholesky"),
         "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
-                   "n": n, "nnz_lower": int(sym.nnz), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
+        "config": {"workload": (f"unsymmetric 3D 19-point stencil {N}^3 (5% of entries dropped one-sidedly), diagonally dominant, "
+                                f"no-pivot LU fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if lu else
+                               f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
+                   "n": n, "nnz_input": int(nnz_in), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
                    "F_struct": F_struct, "F_exec": F_exec,
                    "parallelism": "1 matrix per GPU (independent)" if ngpu > 1 else "single GPU",
                    "exec_GFLOPs": round(F_exec * ngpu / (elapsed / args.steps) / 1e9, 2),
@@ -117,13 +132,13 @@ def main():
         # HBM traffic of that kernel: not measurable live (PMC counters need rocprofv3); taken from the committed
         # PMC passes of this exact workload when they exist (profiles/*_pmc_traffic_128cubed.json, bytes per launch)
         traffic = None
-        if N == 128:
+        if N == 128 and not lu:
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_128cubed.json")))
             if files:
                 with open(files[-1]) as f:
                     traffic = json.load(f).get("k_gemm<1>", {}).get("hbm_bytes_per_launch")
-        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<1> (Schur update, fused scatter)",
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<1> (Schur update, fused scatter%s)" % (", L and U^T sides" if lu else ""),
                            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                            "traffic_note": "HBM bytes per launch of k_gemm<1> from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
@@ -141,7 +156,7 @@ def main():
     if args.check and rank == 0:
         import oracle
         Lsx = plan.get_factor()
-        res, _ = oracle.chol_residual(sym, Lsx)
+        res, _ = (oracle.lu_residual if lu else oracle.chol_residual)(sym, Lsx)
         out["config"]["residual"] = res
         del Lsx
 
@@ -149,14 +164,14 @@ def main():
         import oracle
         threads = args.cpu_threads or min(os.cpu_count() or 1, 16)   # reference: min(omp_max, 16), SparseFrame.c:3357
         binfo = oracle.blas_init("auto", threads=threads)
-        M = args.cpu_grid
-        n2, Cp2, Ci2, Cx2 = sf.gen.laplacian_lower(M, M, M)
-        sym2 = sf.analyze(n2, Cp2, Ci2, Cx2, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU)
-        oracle.chol_factorize(sym2)   # warm-up: first-touch page faults dominated the reference probe
-        _, info, st = oracle.chol_factorize(sym2)
+        M = min(args.cpu_grid, 56) if lu else args.cpu_grid
+        n2, sym2, _ = make(M)
+        cpu_factorize = oracle.lu_factorize if lu else oracle.chol_factorize
+        cpu_factorize(sym2)   # warm-up: first-touch page faults dominated the reference probe
+        _, info, st = cpu_factorize(sym2)
         out["cpu_baseline"] = {"value": round(sym2.flops_struct / st["seconds"] / 1e9, 2), "unit": "GFLOP/s",
                                "cores": int(binfo["threads"]), "kind": "port",
-                               "sample": f"3D 7-point Laplacian {M}^3 (same generator and ordering), full numeric "
+                               "sample": f"{'unsymmetric 19-point stencil' if lu else '3D 7-point Laplacian'} {M}^3 (same generator and ordering), full numeric "
                                          f"factorization, F_struct {sym2.flops_struct:.3e}, {st['seconds']:.2f} s, "
                                          f"1 tree worker x {binfo['threads']} BLAS threads, "
                                          f"{os.path.basename(binfo['name'])}",

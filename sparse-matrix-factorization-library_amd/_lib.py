@@ -15,7 +15,11 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C sparse-matrix-factorization-library_amd/csrc`). There is no Python/CPU fallback.")
 
-lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+lib = C.CDLL(LIB_PATH)
+LU_LIB_PATH = os.path.join(_HERE, "libsparseframe_lu_hip.so")
+if not os.path.exists(LU_LIB_PATH):
+    raise ImportError(f"{LU_LIB_PATH} is missing: run __graft_entry__.build()")
+lu_lib = C.CDLL(LU_LIB_PATH)      # same entry-point names over the LU struct layout (as the reference's LU/Lib)
 
 c_long_p = C.POINTER(C.c_int64)
 c_double_p = C.POINTER(C.c_double)
@@ -38,6 +42,10 @@ lib.sf_symbolic_float_array.argtypes = [C.c_void_p, C.c_char_p, c_long_p]
 lib.sf_symbolic_float_array.restype = c_double_p
 lib.sf_symbolic_flops.argtypes = [C.c_void_p, C.c_int]
 lib.sf_symbolic_flops.restype = C.c_double
+lib.sf_device_memory.argtypes = [C.c_int]
+lib.sf_device_memory.restype = C.c_size_t
+lib.sf_reference_slot_size.argtypes = [C.c_int, C.c_size_t]
+lib.sf_reference_slot_size.restype = C.c_size_t
 lib.sf_grid_nd_perm.argtypes = [C.c_int64] * 5 + [c_long_p]
 lib.sf_grid_nd_perm.restype = C.c_int
 

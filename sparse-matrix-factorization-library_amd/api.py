@@ -14,7 +14,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import lib, check, c_long_p, c_double_p, SparseFrameError
+from ._lib import lib, lu_lib, check, c_long_p, c_double_p, SparseFrameError
 
 # devSlotSize the reference computes (SparseFrame.c:82-87,199) for 288 GiB devices
 REFERENCE_SLOT_1GPU = 8_694_792_192     # 1 device  -> numSplit 4
@@ -283,6 +283,51 @@ for _name, _args in (("SparseFrame_allocate_gpu", [C.POINTER(CommonInfoStruct), 
     _f.restype = C.c_int
 
 
+class LUMatrixInfoStruct(C.Structure):     # LU/Include/info.h:70-163
+    _fields_ = [("serial", C.c_int), ("path", C.c_char_p), ("file", C.c_void_p),
+                ("factorizeType", C.c_int), ("isSymmetric", C.c_int), ("isComplex", C.c_int),
+                ("ncol", C.c_int64), ("nrow", C.c_int64), ("nzmax", C.c_int64),
+                ("Tj", c_long_p), ("Ti", c_long_p), ("Tx", c_double_p),
+                ("Cp", c_long_p), ("Ci", c_long_p), ("Cx", c_double_p),
+                ("nzCPCT", C.c_int64), ("CPCTp", c_long_p), ("CPCTi", c_long_p),
+                ("Lp", c_long_p), ("Li", c_long_p), ("Lx", c_double_p),
+                ("LTp", c_long_p), ("LTi", c_long_p), ("LTx", c_double_p),
+                ("Up", c_long_p), ("Ui", c_long_p), ("Ux", c_double_p),
+                ("UTp", c_long_p), ("UTi", c_long_p), ("UTx", c_double_p),
+                ("permMethod", C.c_int), ("PivInv", c_long_p),
+                ("Perm", c_long_p), ("Parent", c_long_p), ("Post", c_long_p), ("ColCount", c_long_p),
+                ("nsuper", C.c_int64), ("Super", c_long_p), ("SuperMap", c_long_p), ("Sparent", c_long_p),
+                ("nsleaf", C.c_int64), ("LeafQueue", c_long_p),
+                ("isize", C.c_int64), ("xsize", C.c_int64),
+                ("Lsip", c_long_p), ("Lsxp", c_long_p), ("Lsi", c_long_p), ("Lsx", c_double_p),
+                ("csize", C.c_int64), ("nstage", C.c_int64),
+                ("ST_Map", c_long_p), ("ST_Pointer", c_long_p), ("ST_Index", c_long_p), ("ST_Parent", c_long_p),
+                ("Aoffset", C.POINTER(C.c_size_t)), ("Moffset", C.POINTER(C.c_size_t)),
+                ("workspace", C.c_void_p), ("workSize", C.c_size_t),
+                ("Bx", c_double_p), ("Xx", c_double_p), ("Rx", c_double_p),
+                ("residual", C.c_double),
+                ("readTime", C.c_double), ("analyzeTime", C.c_double),
+                ("factorizeTime", C.c_double), ("solveTime", C.c_double)]
+
+
+for _name, _args in (("SparseFrame_allocate_gpu", [C.POINTER(CommonInfoStruct), C.POINTER(C.c_void_p)]),
+                     ("SparseFrame_free_gpu", [C.POINTER(CommonInfoStruct), C.POINTER(C.c_void_p)]),
+                     ("SparseFrame_initialize_matrix", [C.POINTER(LUMatrixInfoStruct)]),
+                     ("SparseFrame_read_matrix", [C.POINTER(LUMatrixInfoStruct)]),
+                     ("SparseFrame_set_matrix_csc", [C.POINTER(LUMatrixInfoStruct), C.c_int64, C.c_int64,
+                                                     c_long_p, c_long_p, c_double_p, C.c_int]),
+                     ("SparseFrame_set_perm", [C.POINTER(LUMatrixInfoStruct), c_long_p]),
+                     ("SparseFrame_analyze", [C.POINTER(CommonInfoStruct), C.POINTER(LUMatrixInfoStruct)]),
+                     ("SparseFrame_factorize", [C.POINTER(CommonInfoStruct), C.c_void_p, C.POINTER(LUMatrixInfoStruct)]),
+                     ("SparseFrame_factorize_supernodal", [C.POINTER(CommonInfoStruct), C.c_void_p, C.POINTER(LUMatrixInfoStruct)]),
+                     ("SparseFrame_solve_supernodal", [C.POINTER(LUMatrixInfoStruct)]),
+                     ("SparseFrame_validate", [C.POINTER(LUMatrixInfoStruct)]),
+                     ("SparseFrame_cleanup_matrix", [C.POINTER(LUMatrixInfoStruct)])):
+    _f = getattr(lu_lib, _name)
+    _f.argtypes = _args
+    _f.restype = C.c_int
+
+
 class CommonInfo:
     """common_info_struct + the opaque gpu_info list (SparseFrame_allocate_gpu / _free_gpu)."""
 
@@ -306,39 +351,42 @@ class CommonInfo:
 
 
 class MatrixInfo:
-    """matrix_info_struct driven through the reference's stage functions."""
+    """matrix_info_struct driven through the reference's stage functions (Cholesky library)."""
+    _lib = lib
+    _struct = MatrixInfoStruct
 
     def __init__(self, serial=0):
-        self.c = MatrixInfoStruct()
+        self.c = self._struct()
         self.c.serial = serial
-        lib.SparseFrame_initialize_matrix(C.byref(self.c))
+        self._lib.SparseFrame_initialize_matrix(C.byref(self.c))
 
     def set_csc(self, n, Cp, Ci, Cx, symmetric=True):
+        """symmetric=True: one triangle (Cholesky, or LU of a symmetric matrix); False: whole matrix (LU only)"""
         Cp, Ci, Cx = _i64(Cp), _i64(Ci), _f64(Cx)
-        check(lib.SparseFrame_set_matrix_csc(C.byref(self.c), n, len(Ci), _lp(Cp), _lp(Ci), _dp(Cx),
+        check(self._lib.SparseFrame_set_matrix_csc(C.byref(self.c), n, len(Ci), _lp(Cp), _lp(Ci), _dp(Cx),
                                              1 if symmetric else 0), "SparseFrame_set_matrix_csc")
 
     def read(self, path):
         self._path = str(path).encode()
         self.c.path = self._path
-        check(lib.SparseFrame_read_matrix(C.byref(self.c)), "SparseFrame_read_matrix")
+        check(self._lib.SparseFrame_read_matrix(C.byref(self.c)), "SparseFrame_read_matrix")
 
     def set_perm(self, perm):
         perm = _i64(perm)
-        check(lib.SparseFrame_set_perm(C.byref(self.c), _lp(perm)), "SparseFrame_set_perm")
+        check(self._lib.SparseFrame_set_perm(C.byref(self.c), _lp(perm)), "SparseFrame_set_perm")
 
     def analyze(self, common):
-        check(lib.SparseFrame_analyze(C.byref(common.c), C.byref(self.c)), "SparseFrame_analyze")
+        check(self._lib.SparseFrame_analyze(C.byref(common.c), C.byref(self.c)), "SparseFrame_analyze")
 
     def factorize(self, common):
-        check(lib.SparseFrame_factorize(C.byref(common.c), common.gpu_list, C.byref(self.c)), "SparseFrame_factorize")
+        check(self._lib.SparseFrame_factorize(C.byref(common.c), common.gpu_list, C.byref(self.c)), "SparseFrame_factorize")
 
     def validate(self):
-        check(lib.SparseFrame_validate(C.byref(self.c)), "SparseFrame_validate")
+        check(self._lib.SparseFrame_validate(C.byref(self.c)), "SparseFrame_validate")
         return float(self.c.residual)
 
     def cleanup(self):
-        lib.SparseFrame_cleanup_matrix(C.byref(self.c))
+        self._lib.SparseFrame_cleanup_matrix(C.byref(self.c))
 
     def array(self, name, length):
         p = getattr(self.c, name)
@@ -351,3 +399,9 @@ class MatrixInfo:
             self.cleanup()
         except Exception:
             pass
+
+
+class LUMatrixInfo(MatrixInfo):
+    """the same stage functions from the LU library (libsparseframe_lu_hip.so, LU struct layout)"""
+    _lib = lu_lib
+    _struct = LUMatrixInfoStruct

@@ -124,6 +124,24 @@ int sf_device_count(void) {
     return n;
 }
 
+size_t sf_device_memory(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    return (size_t)prop.totalGlobalMem;
+}
+
+size_t sf_reference_slot_size(int ndev, size_t min_mem) {
+    if (ndev <= 0) return 0;
+    // C:36-41 numSplit = max(GPU_SPLIT_LIMIT / numGPU_physical, 1), GPU_SPLIT_LIMIT = 4 (parameter.h:19);
+    // C:82-87: (mem - 64 MiB) * 0.9 / numSplit / 8 slots, rounded down to 1 MiB; C:199 devSlotSize = that
+    const int numSplit = std::max(4 / ndev, 1);
+    size_t m = (size_t)(((double)min_mem - 64.0 * (0x400 * 0x400)) * 0.9);
+    m /= numSplit;
+    m /= 8;
+    m -= m % (0x400 * 0x400);
+    return m;
+}
+
 int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
     (void)hipSetDevice(p->device);
@@ -634,14 +652,8 @@ int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_
         min_mem = std::min(min_mem, (size_t)prop.totalGlobalMem);
     }
     if (ndev > 0 && min_mem != (size_t)-1) {
-        // the reference's slot formula (C:82-87, C:199) with its numSplit = max(4 / numGPU, 1)
-        const int numSplit = std::max(4 / ndev, 1);
-        size_t m = (size_t)(((double)min_mem - 64.0 * (0x400 * 0x400)) * 0.9);
-        m /= numSplit;
-        m /= 8;
-        m -= m % (0x400 * 0x400);
-        common->devSlotSize = m;
-        common->minDevMemSize = m * 8;
+        common->devSlotSize = sf_reference_slot_size(ndev, min_mem);
+        common->minDevMemSize = common->devSlotSize * 8;
     } else {
         const char* env = getenv("SF_DEVSLOT");
         common->devSlotSize = env ? (size_t)strtoull(env, nullptr, 10) : ((size_t)1 << 30);

@@ -1,0 +1,348 @@
+// libsparseframe_lu_hip.so: the reference's struct-based entry points over the LU layout of matrix_info_struct
+// (LU/Include/info.h), forwarding to the flat ABI of libsparseframe_hip.so (sf_symbolic_create_lu, sf_lu_plan_*).
+// Reference file: LU/Source/SparseFrame.c ("L:").
+#include <sparseframe_lu_hip.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <time.h>
+#include <vector>
+
+namespace {
+
+double wall_seconds() {
+    struct timespec tp;
+    clock_gettime(CLOCK_REALTIME, &tp);
+    return tp.tv_sec + (double)tp.tv_nsec / 1.0e9;
+}
+
+void free_and_null(void** p) {
+    if (*p) free(*p);
+    *p = nullptr;
+}
+#define SF_FREE(field) free_and_null((void**)&(mi->field))
+
+sf_long* dup_long(const sf_symbolic* S, const char* name, sf_long min_len = 1) {
+    sf_long len = 0;
+    const sf_long* src = sf_symbolic_long_array(S, name, &len);
+    sf_long* p = (sf_long*)calloc((size_t)(len > min_len ? len : min_len), sizeof(sf_long));
+    if (p && src && len > 0) memcpy(p, src, (size_t)len * sizeof(sf_long));
+    return p;
+}
+sf_float* dup_float(const sf_symbolic* S, const char* name) {
+    sf_long len = 0;
+    const sf_float* src = sf_symbolic_float_array(S, name, &len);
+    sf_float* p = (sf_float*)calloc((size_t)(len > 1 ? len : 1), sizeof(sf_float));
+    if (p && src && len > 0) memcpy(p, src, (size_t)len * sizeof(sf_float));
+    return p;
+}
+
+}  // namespace
+
+struct gpu_info_struct {
+    int gpuIndex_physical;
+    size_t devMemSize;
+};
+
+extern "C" {
+
+long sf_lu_abi_layout(const char* name) {
+    if (!name) return -1;
+    const std::string k(name);
+    if (k == "sizeof_common") return (long)sizeof(struct common_info_struct);
+    if (k == "sizeof_matrix") return (long)sizeof(struct matrix_info_struct);
+    if (k == "offsetof_Lsx") return (long)offsetof(struct matrix_info_struct, Lsx);
+    if (k == "offsetof_Up") return (long)offsetof(struct matrix_info_struct, Up);
+    if (k == "offsetof_workspace") return (long)offsetof(struct matrix_info_struct, workspace);
+    if (k == "offsetof_residual") return (long)offsetof(struct matrix_info_struct, residual);
+    return -1;
+}
+
+int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {   // L:16-285
+    if (!common || !list) return 1;
+    const int ndev = sf_device_count();
+    common->numGPU_physical = ndev;
+    common->numGPU = ndev;
+    common->numCPU = 0;
+    common->minHostMemSize = 0;
+    *list = (struct gpu_info_struct*)calloc(ndev > 0 ? ndev : 1, sizeof(struct gpu_info_struct));
+    if (!*list) return 1;
+    size_t min_mem = (size_t)-1;
+    for (int d = 0; d < ndev; ++d) {
+        (*list)[d].gpuIndex_physical = d;
+        (*list)[d].devMemSize = sf_device_memory(d);
+        if ((*list)[d].devMemSize < min_mem) min_mem = (*list)[d].devMemSize;
+    }
+    if (ndev > 0) {
+        common->devSlotSize = sf_reference_slot_size(ndev, min_mem);
+        common->minDevMemSize = common->devSlotSize * 8;
+    } else {
+        const char* env = getenv("SF_DEVSLOT");
+        common->devSlotSize = env ? (size_t)strtoull(env, nullptr, 10) : ((size_t)1 << 30);
+        common->minDevMemSize = 0;
+    }
+    return 0;
+}
+
+int SparseFrame_free_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {   // L:287-366
+    if (!list || !*list) return 1;
+    free(*list);
+    *list = nullptr;
+    if (common) common->numGPU = 0;
+    return 0;
+}
+
+int SparseFrame_initialize_matrix(struct matrix_info_struct* mi) {   // L:675-746
+    if (!mi) return 1;
+    const int serial = mi->serial;
+    const char* path = mi->path;
+    memset(mi, 0, sizeof(*mi));
+    mi->serial = serial;
+    mi->path = path;
+    mi->factorizeType = TYPE_LU;
+    mi->permMethod = PERM_IDENTITY;
+    return 0;
+}
+
+int SparseFrame_set_matrix_csc(struct matrix_info_struct* mi, sf_long nrow, sf_long nz,
+                               const sf_long* Cp, const sf_long* Ci, const sf_float* Cx, int isSymmetric) {
+    if (!mi || nrow < 0 || nz < 0 || !Cp || (nz > 0 && (!Ci || !Cx))) return 1;
+    if (Cp[0] != 0 || Cp[nrow] != nz) return 1;
+    SF_FREE(Cp); SF_FREE(Ci); SF_FREE(Cx); SF_FREE(workspace);
+    mi->isSymmetric = isSymmetric;
+    mi->isComplex = 0;
+    mi->nrow = mi->ncol = nrow;
+    mi->nzmax = nz;
+    mi->Cp = (sf_long*)malloc((nrow + 1) * sizeof(sf_long));
+    mi->Ci = (sf_long*)malloc((nz > 0 ? nz : 1) * sizeof(sf_long));
+    mi->Cx = (sf_float*)malloc((nz > 0 ? nz : 1) * sizeof(sf_float));
+    mi->workSize = (size_t)(10 * nrow + (2 * nz - nrow > 0 ? 2 * nz - nrow : 0) + 1) * sizeof(sf_long);   // L:775-780
+    mi->workspace = malloc(mi->workSize);
+    if (!mi->Cp || !mi->Ci || !mi->Cx || !mi->workspace) return 1;
+    memcpy(mi->Cp, Cp, (nrow + 1) * sizeof(sf_long));
+    if (nz > 0) {
+        memcpy(mi->Ci, Ci, nz * sizeof(sf_long));
+        memcpy(mi->Cx, Cx, nz * sizeof(sf_float));
+    }
+    return 0;
+}
+
+// MatrixMarket coordinate real {symmetric|general}; explicit zeros dropped (L:496); counting-sort compress (L:526-587)
+int SparseFrame_read_matrix(struct matrix_info_struct* mi) {
+    if (!mi || !mi->path) return 1;
+    const double t0 = wall_seconds();
+    FILE* f = fopen(mi->path, "r");
+    if (!f) return 1;
+    char* line = nullptr;
+    size_t cap = 0;
+    int rc = 1, symmetric = 0;
+    long nrow = 0, ncol = 0, nzmax = 0;
+    std::vector<sf_long> Ti, Tj;
+    std::vector<double> Tx;
+    do {
+        ssize_t got;
+        while ((got = getline(&line, &cap, f)) != -1 && line[0] == '\n') {}
+        if (got == -1 || strncmp(line, "%%MatrixMarket", 14) != 0) break;
+        char s0[64], s1[64], s2[64], s3[64], s4[64];
+        s3[0] = s4[0] = 0;
+        sscanf(line, "%63s %63s %63s %63s %63s", s0, s1, s2, s3, s4);
+        symmetric = strcmp(s4, "symmetric") == 0;
+        if (strcmp(s3, "real") != 0 && strcmp(s3, "integer") != 0) break;
+        while ((got = getline(&line, &cap, f)) != -1 && (line[0] == '%' || line[0] == '\n')) {}
+        if (got == -1 || sscanf(line, "%ld %ld %ld", &nrow, &ncol, &nzmax) != 3) break;
+        if (nrow != ncol || nrow < 0 || nzmax < 0) break;
+        bool bad = false;
+        while (getline(&line, &cap, f) != -1) {
+            if (line[0] == '\n' || line[0] == 0) continue;
+            long i, j; double x;
+            if (sscanf(line, "%ld %ld %lg", &i, &j, &x) < 3) { bad = true; break; }
+            if (x != 0) {
+                if ((long)Tx.size() >= nzmax || i < 1 || j < 1 || i > nrow || j > ncol) { bad = true; break; }
+                Ti.push_back(i - 1); Tj.push_back(j - 1); Tx.push_back(x);
+            }
+        }
+        if (!bad) rc = 0;
+    } while (0);
+    free(line);
+    fclose(f);
+    if (rc) return rc;
+    const sf_long nz = (sf_long)Tx.size();
+    std::vector<sf_long> Cp(ncol + 1, 0), Ci(nz > 0 ? nz : 1);
+    std::vector<double> Cx(nz > 0 ? nz : 1);
+    for (sf_long k = 0; k < nz; ++k) Cp[Tj[k] + 1]++;
+    for (sf_long j = 0; j < ncol; ++j) Cp[j + 1] += Cp[j];
+    std::vector<sf_long> fill(Cp.begin(), Cp.end() - 1);
+    for (sf_long k = 0; k < nz; ++k) { const sf_long p = fill[Tj[k]]++; Ci[p] = Ti[k]; Cx[p] = Tx[k]; }
+    rc = SparseFrame_set_matrix_csc(mi, nrow, nz, Cp.data(), Ci.data(), Cx.data(), symmetric);
+    mi->readTime = wall_seconds() - t0;
+    return rc;
+}
+
+int SparseFrame_set_perm(struct matrix_info_struct* mi, const sf_long* perm) {
+    if (!mi || mi->nrow <= 0) return 1;
+    SF_FREE(Perm);
+    if (!perm) { mi->permMethod = PERM_IDENTITY; return 0; }
+    mi->Perm = (sf_long*)malloc(mi->nrow * sizeof(sf_long));
+    if (!mi->Perm) return 1;
+    memcpy(mi->Perm, perm, mi->nrow * sizeof(sf_long));
+    mi->permMethod = PERM_METIS;
+    return 0;
+}
+
+int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_struct* mi) {   // L:2233-2458
+    if (!common || !mi || !mi->Cp) return 1;
+    const double t0 = wall_seconds();
+    sf_symbolic* S = nullptr;
+    const sf_long* perm = (mi->permMethod != PERM_IDENTITY) ? mi->Perm : nullptr;
+    if (sf_symbolic_create_lu(&S, mi->nrow, mi->Cp, mi->Ci, mi->Cx, perm, common->devSlotSize, mi->isSymmetric)) return 1;
+
+    SF_FREE(Lp); SF_FREE(Li); SF_FREE(Lx); SF_FREE(LTp); SF_FREE(LTi); SF_FREE(LTx);
+    SF_FREE(Up); SF_FREE(Ui); SF_FREE(Ux); SF_FREE(UTp); SF_FREE(UTi); SF_FREE(UTx);
+    SF_FREE(Perm); SF_FREE(Parent); SF_FREE(Post); SF_FREE(ColCount);
+    SF_FREE(Super); SF_FREE(SuperMap); SF_FREE(Sparent); SF_FREE(LeafQueue);
+    SF_FREE(Lsip); SF_FREE(Lsxp); SF_FREE(Lsi); SF_FREE(Lsx);
+    SF_FREE(ST_Map); SF_FREE(ST_Pointer); SF_FREE(ST_Index); SF_FREE(Aoffset); SF_FREE(Moffset);
+
+    mi->Lp = dup_long(S, "Lp"); mi->Li = dup_long(S, "Li"); mi->Lx = dup_float(S, "Lx");
+    mi->LTp = dup_long(S, "LTp"); mi->LTi = dup_long(S, "LTi"); mi->LTx = dup_float(S, "LTx");
+    if (!mi->isSymmetric) {
+        mi->Up = dup_long(S, "Up"); mi->Ui = dup_long(S, "Ui"); mi->Ux = dup_float(S, "Ux");
+        mi->UTp = dup_long(S, "UTp"); mi->UTi = dup_long(S, "UTi"); mi->UTx = dup_float(S, "UTx");
+    }
+    mi->Perm = dup_long(S, "Perm");
+    mi->Parent = dup_long(S, "Parent");
+    mi->Post = dup_long(S, "Post");
+    mi->ColCount = dup_long(S, "ColCount");
+    mi->nsuper = sf_symbolic_scalar(S, "nsuper");
+    mi->Super = dup_long(S, "Super", mi->nrow + 1);      // the reference allocates nrow+1 / nrow entries (L:2449-2451)
+    mi->SuperMap = dup_long(S, "SuperMap");
+    mi->Sparent = dup_long(S, "Sparent", mi->nrow);
+    mi->nsleaf = sf_symbolic_scalar(S, "nsleaf");
+    mi->LeafQueue = dup_long(S, "LeafQueue");
+    mi->isize = sf_symbolic_scalar(S, "isize");
+    mi->xsize = sf_symbolic_scalar(S, "xsize");
+    mi->Lsip = dup_long(S, "Lsip"); mi->Lsxp = dup_long(S, "Lsxp"); mi->Lsi = dup_long(S, "Lsi");
+    mi->Lsx = (sf_float*)malloc((size_t)(mi->xsize > 0 ? mi->xsize : 1) * sizeof(sf_float));
+    mi->csize = sf_symbolic_scalar(S, "csize");
+    mi->nstage = sf_symbolic_scalar(S, "nstage");
+    mi->ST_Map = dup_long(S, "ST_Map"); mi->ST_Pointer = dup_long(S, "ST_Pointer"); mi->ST_Index = dup_long(S, "ST_Index");
+    mi->ST_Parent = nullptr;
+    mi->Aoffset = (size_t*)dup_long(S, "Aoffset");      // size_t and int64_t have the same size and non-negative values
+    mi->Moffset = (size_t*)dup_long(S, "Moffset");
+    sf_symbolic_destroy(S);
+    mi->analyzeTime = wall_seconds() - t0;
+    return mi->Lsx ? 0 : 1;
+}
+
+int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct gpu_info_struct* list,
+                                     struct matrix_info_struct* mi) {   // L:2668-3573
+    if (!common || !mi || !mi->Lsx) return SF_ERR_ARG;
+    if (common->numGPU <= 0 || !list) {
+        fprintf(stderr, "[sparseframe-hip] SparseFrame_factorize (LU): no GPU handler; no CPU fallback\n");
+        return SF_ERR_NO_DEVICE;
+    }
+    sf_lu_plan* plan = nullptr;
+    int rc = sf_lu_plan_create(&plan, list[0].gpuIndex_physical, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap,
+                               mi->Lsip, mi->Lsi, mi->Lsxp, mi->Lp, mi->Li,
+                               mi->isSymmetric ? nullptr : mi->Up, mi->isSymmetric ? nullptr : mi->Ui);
+    if (rc) return rc;
+    rc = sf_lu_plan_set_values(plan, mi->Lx, mi->isSymmetric ? nullptr : mi->Ux);
+    if (!rc) rc = sf_lu_plan_factorize(plan, 1);
+    const int rc2 = sf_lu_plan_get_factor(plan, mi->Lsx);
+    sf_lu_plan_destroy(plan);
+    return rc ? rc : rc2;
+}
+
+int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {
+    const double t0 = wall_seconds();
+    const int rc = SparseFrame_factorize_supernodal(common, list, mi);
+    if (mi) mi->factorizeTime = wall_seconds() - t0;
+    return rc;
+}
+
+// unit-lower forward substitution, then backward with U11 (packed in the diagonal block, accessed transposed)
+// and the U12^T block at row offset nsrow - nscol (L:3592-3700)
+int SparseFrame_solve_supernodal(struct matrix_info_struct* mi) {
+    if (!mi || !mi->Lsx || !mi->Bx || !mi->Xx) return 1;
+    const double t0 = wall_seconds();
+    double* x = mi->Xx;
+    memcpy(x, mi->Bx, mi->nrow * sizeof(double));
+    for (sf_long s = 0; s < mi->nsuper; ++s) {
+        const sf_long nscol = mi->Super[s + 1] - mi->Super[s], nsrow = mi->Lsip[s + 1] - mi->Lsip[s], lda = 2 * nsrow - nscol;
+        const sf_long* rows = mi->Lsi + mi->Lsip[s];
+        const double* P = mi->Lsx + mi->Lsxp[s];
+        for (sf_long c = 0; c < nscol; ++c) {
+            const double xj = x[rows[c]];
+            const double* col = P + c * lda;
+            for (sf_long r = c + 1; r < nsrow; ++r) x[rows[r]] -= col[r] * xj;
+        }
+    }
+    for (sf_long s = mi->nsuper - 1; s >= 0; --s) {
+        const sf_long nscol = mi->Super[s + 1] - mi->Super[s], nsrow = mi->Lsip[s + 1] - mi->Lsip[s], lda = 2 * nsrow - nscol;
+        const sf_long* rows = mi->Lsi + mi->Lsip[s];
+        const double* P = mi->Lsx + mi->Lsxp[s];
+        for (sf_long c = nscol - 1; c >= 0; --c) {
+            double acc = x[rows[c]];
+            for (sf_long r = c + 1; r < nscol; ++r) acc -= P[r * lda + c] * x[rows[r]];                        // U11(c,r)
+            for (sf_long r = nscol; r < nsrow; ++r) acc -= P[(nsrow - nscol) + c * lda + r] * x[rows[r]];       // U12^T
+            x[rows[c]] = acc / P[c * lda + c];
+        }
+    }
+    mi->solveTime = wall_seconds() - t0;
+    return 0;
+}
+
+int SparseFrame_validate(struct matrix_info_struct* mi) {   // L:3702-3858
+    if (!mi || !mi->Lp || !mi->Lsx) return 1;
+    const sf_long n = mi->nrow;
+    SF_FREE(Bx); SF_FREE(Xx); SF_FREE(Rx);
+    mi->Bx = (double*)malloc((n > 0 ? n : 1) * sizeof(double));
+    mi->Xx = (double*)malloc((n > 0 ? n : 1) * sizeof(double));
+    mi->Rx = (double*)malloc((n > 0 ? n : 1) * sizeof(double));
+    if (!mi->Bx || !mi->Xx || !mi->Rx) return 1;
+    for (sf_long i = 0; i < n; ++i) mi->Bx[i] = 1 + i / (double)n;
+    if (SparseFrame_solve_supernodal(mi)) return 1;
+    const sf_long* Up = mi->isSymmetric ? mi->Lp : mi->Up;
+    const sf_long* Ui = mi->isSymmetric ? mi->Li : mi->Ui;
+    const double* Ux = mi->isSymmetric ? mi->Lx : mi->Ux;
+    std::vector<double> colsum(n, 0.0);
+    for (sf_long i = 0; i < n; ++i) mi->Rx[i] = -mi->Bx[i];
+    for (sf_long j = 0; j < n; ++j) {
+        for (sf_long p = mi->Lp[j]; p < mi->Lp[j + 1]; ++p) { mi->Rx[mi->Li[p]] += mi->Lx[p] * mi->Xx[j]; colsum[j] += std::fabs(mi->Lx[p]); }
+        for (sf_long p = Up[j]; p < Up[j + 1]; ++p) {
+            const sf_long i = Ui[p];
+            if (i != j) { mi->Rx[j] += Ux[p] * mi->Xx[i]; colsum[i] += std::fabs(Ux[p]); }
+        }
+    }
+    double anorm = 0, bnorm = 0, xnorm = 0, rnorm = 0;
+    for (sf_long i = 0; i < n; ++i) {
+        anorm = std::fmax(anorm, colsum[i]);
+        bnorm = std::fmax(bnorm, std::fabs(mi->Bx[i]));
+        xnorm = std::fmax(xnorm, std::fabs(mi->Xx[i]));
+        rnorm = std::fmax(rnorm, std::fabs(mi->Rx[i]));
+    }
+    mi->residual = rnorm / (anorm * xnorm + bnorm);
+    return 0;
+}
+
+int SparseFrame_cleanup_matrix(struct matrix_info_struct* mi) {   // L:3860-3922
+    if (!mi) return 1;
+    SF_FREE(Tj); SF_FREE(Ti); SF_FREE(Tx); SF_FREE(Cp); SF_FREE(Ci); SF_FREE(Cx);
+    SF_FREE(CPCTp); SF_FREE(CPCTi);
+    SF_FREE(Lp); SF_FREE(Li); SF_FREE(Lx); SF_FREE(LTp); SF_FREE(LTi); SF_FREE(LTx);
+    SF_FREE(Up); SF_FREE(Ui); SF_FREE(Ux); SF_FREE(UTp); SF_FREE(UTi); SF_FREE(UTx);
+    SF_FREE(PivInv); SF_FREE(Perm); SF_FREE(Post); SF_FREE(Parent); SF_FREE(ColCount);
+    SF_FREE(Super); SF_FREE(SuperMap); SF_FREE(Sparent); SF_FREE(LeafQueue);
+    SF_FREE(Lsip); SF_FREE(Lsxp); SF_FREE(Lsi); SF_FREE(Lsx);
+    SF_FREE(ST_Map); SF_FREE(ST_Pointer); SF_FREE(ST_Index); SF_FREE(Aoffset); SF_FREE(Moffset);
+    SF_FREE(workspace); SF_FREE(Bx); SF_FREE(Xx); SF_FREE(Rx);
+    const double rt = mi->readTime, at = mi->analyzeTime, ft = mi->factorizeTime, st = mi->solveTime, res = mi->residual;
+    SparseFrame_initialize_matrix(mi);
+    mi->readTime = rt; mi->analyzeTime = at; mi->factorizeTime = ft; mi->solveTime = st; mi->residual = res;
+    return 0;
+}
+
+}  // extern "C"

@@ -115,11 +115,14 @@ def arrow_spd_lower(n, width=1):
     return n, Cp, Ci, Cx
 
 
-def unsymmetric_stencil(nx, ny=1, nz=1, extra_per_row=1, seed=2024, reach=1):
+def unsymmetric_stencil(nx, ny=1, nz=1, extra_per_row=1, seed=2024, reach=1, drop=0.0):
     """BASELINE config 5 generator: 3-D stencil of faces + edges within `reach` (19-point for
-    reach=1), plus `extra_per_row` random off-pattern entries per row (structurally unsymmetric), independent
+    reach=1), made structurally unsymmetric by `extra_per_row` random off-pattern entries per row and/or by
+    dropping a fraction `drop` of the off-diagonal entries (each (i,j) independently of (j,i)); independent
     values U(-1,-0.5) for (i,j) and (j,i), diagonal 1 + sum of |row| + |column| so that NO-PIVOT LU is stable
-    (the reference never pivots).  Returns the whole matrix in CSC (n, Cp, Ci, Cx)."""
+    (the reference never pivots).  Returns the whole matrix in CSC (n, Cp, Ci, Cx).
+    Note: random long-range extras destroy the grid separators (fill explodes under a geometric ordering);
+    the bench workload therefore uses drop > 0 and extra_per_row = 0."""
     n = nx * ny * nz
     rng = np.random.default_rng(seed)
     idx = np.arange(n, dtype=np.int64)
@@ -147,6 +150,9 @@ def unsymmetric_stencil(nx, ny=1, nz=1, extra_per_row=1, seed=2024, reach=1):
     rows, cols = np.concatenate(rows), np.concatenate(cols)
     key = np.unique(cols * n + rows)
     cols, rows = key // n, key % n
+    if drop > 0:
+        keep = rng.random(rows.size) >= drop
+        rows, cols = rows[keep], cols[keep]
     vals = rng.uniform(-1.0, -0.5, size=rows.size)
     d = np.ones(n)
     np.add.at(d, rows, np.abs(vals))

@@ -132,3 +132,49 @@ def test_lu_zero_pivot_is_reported():
     with pytest.raises(sf.SparseFrameError, match="SF_ERR_NOT_POSDEF"):
         plan.factorize()
     plan.close()
+
+
+def test_lu_struct_api_host_side(oracle):
+    """LU library, reference call order (LU/Source/SparseFrame.c:3997-4024) with an oracle-made factor"""
+    import ctypes as C
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(6, 6, 6, seed=11)
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(nd_perm_py(6, 6, 6))
+    mi.analyze(common)
+    S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(6, 6, 6), 1 << 30, "lu", False)
+    assert (mi.c.nsuper, mi.c.xsize, mi.c.csize, mi.c.isize) == (S.nsuper, S.xsize, S.csize, S.isize)
+    for k, ln in (("Ui", S.unz), ("Up", n + 1), ("Li", S.nnz), ("Lsi", S.isize), ("Lsxp", S.nsuper + 1), ("Perm", n)):
+        assert np.array_equal(mi.array(k, ln), getattr(S, k)), k
+    Lsx, info, _ = oracle.lu_factorize(S)
+    assert info == 0
+    C.memmove(mi.c.Lsx, Lsx.ctypes.data, Lsx.nbytes)
+    res = mi.validate()
+    want, x = oracle.lu_residual(S, Lsx)
+    assert res <= TOL_RESIDUAL and abs(res - want) <= 1e-16
+    assert np.allclose(mi.array("Xx", n), x, rtol=1e-14, atol=0)
+    mi.cleanup()
+    assert not mi.c.Lsx and not mi.c.Up
+
+
+@pytest.mark.gpu
+def test_lu_struct_entry_points_end_to_end(oracle, tmp_path):
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(10, 10, 10, seed=12)
+    path = tmp_path / "u.mtx"
+    gen.write_matrix_market(path, n, Cp, Ci, Cx, symmetric=False)
+    common = sf.CommonInfo()
+    common.c.devSlotSize = 1 << 30
+    mi = sf.LUMatrixInfo()
+    mi.read(path)
+    assert (mi.c.isSymmetric, mi.c.nzmax) == (0, len(Ci))
+    mi.set_perm(nd_perm_py(10, 10, 10))
+    mi.analyze(common)
+    mi.factorize(common)
+    res = mi.validate()
+    assert res <= TOL_RESIDUAL
+    S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(10, 10, 10), 1 << 30, "lu", False)
+    ref, info, _ = oracle.lu_factorize(S)
+    assert rel_err(mi.array("Lsx", S.xsize).copy(), ref) <= TOL_FACTOR
+    mi.cleanup()
+    common.close()
