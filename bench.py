@@ -8,8 +8,10 @@ geometric nested dissection, devSlotSize = the reference's formula for one 288 G
 A "step" = one complete numeric factorization (assemble + every panel + every Schur update) with the
 matrix values, the symbolic structure and the task tables already resident in HBM; the factor stays
 in HBM.  value = F_struct * N / t  with  F_struct = sum_j ColCount_j^2  (SURVEY 8d).
-N > 1: one process per GPU, each factorizes its own matrix of the same shape (the reference's own
-multi-matrix mode, SparseFrame.c:3375); no data-path collective; "weak" scaling.
+N > 1 (default --mp subtree): ONE factorization of the same matrix sharded over the N GPUs by elimination-tree
+subtrees: own subtrees -> one RCCL sum all-reduce of the top-panel region -> replicated top
+supernodes; "strong" scaling (the Amdahl bound of subtree-only sharding is printed in config.sharding).
+--mp replicas: one independent matrix per GPU (the reference's multi-matrix mode, SparseFrame.c:3375), "weak".
 
 The JSON line also carries
   roofline     : the Schur-update kernel (k_gemm<1>: fp64 MFMA GEMM + fused mapped scatter), executed
@@ -39,6 +41,8 @@ def main():
                     help="cholesky: 3-D 7-pt Laplacian (the headline workload); lu: unsymmetric 19-pt stencil, no-pivot LU")
     ap.add_argument("--cpu-grid", type=int, default=72, help="N of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="BLAS threads of the CPU baseline (0 = min(cores,16))")
+    ap.add_argument("--mp", choices=["subtree", "replicas"], default="subtree",
+                    help="N > 1: shard one matrix by elimination-tree subtrees (default) or run one matrix per GPU")
     ap.add_argument("--check", action="store_true", help="download the factor and check the residual on the host")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -78,7 +82,12 @@ def main():
     F_struct, F_exec = sym.flops_struct, sym.flops_exec
 
     t0 = time.time()
-    if lu:
+    sharded = None
+    if world > 1 and args.mp == "subtree" and not lu:
+        sharded = sf.ShardedCholesky(sym, rank, world, device=local_rank)
+        sharded.set_values(sym.Lx)
+        plan = sharded.engine.plan
+    elif lu:
         plan = sf.LUPlan(sym, device=local_rank)
         plan.set_values(sym.Lx, sym.Ux)
     else:
@@ -92,12 +101,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def step(sync):
+        if sharded is not None:
+            sharded.factorize()
+        else:
+            plan.factorize(sync=sync)
+
     for _ in range(args.warmup):
-        plan.factorize(sync=True)
+        step(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan.factorize(sync=False)
+        step(False)
     plan.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -106,24 +121,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = F_struct * ngpu / (elapsed / args.steps) / 1e9
+    units = 1 if sharded is not None else ngpu        # matrices factorized per step by the whole job
+    value = F_struct * units / (elapsed / args.steps) / 1e9
 
     out = {
         "metric": "numeric-factorization GFLOP/s (supernodal %s)" % ("no-pivot LU" if lu else "Cholesky"),
         "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if sharded is not None else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"unsymmetric 3D 19-point stencil {N}^3 (5% of entries dropped one-sidedly), diagonally dominant, "
                                 f"no-pivot LU fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if lu else
                                f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
                    "n": n, "nnz_input": int(nnz_in), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
                    "F_struct": F_struct, "F_exec": F_exec,
-                   "parallelism": "1 matrix per GPU (independent)" if ngpu > 1 else "single GPU",
-                   "exec_GFLOPs": round(F_exec * ngpu / (elapsed / args.steps) / 1e9, 2),
+                   "parallelism": ("elimination-tree subtrees sharded over the GPUs, one RCCL all-reduce of the top panels, "
+                                   "top supernodes replicated") if sharded is not None else
+                                  ("1 matrix per GPU (independent)" if ngpu > 1 else "single GPU"),
+                   "sharding": sharded.plan_info() if sharded is not None else None,
+                   "exec_GFLOPs": round(F_exec * units / (elapsed / args.steps) / 1e9, 2),
                    "host_analyze_s": round(t_analyze, 2), "plan_create_s": round(t_plan, 2)},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and sharded is None:
         plan.set_profiling(True)
         plan.factorize(sync=True)
         plan.set_profiling(False)
@@ -153,7 +172,14 @@ def main():
                            "flops_update": plan.stat("flops_update"),
                            "launches": int(plan.stat("launches")), "levels": int(plan.stat("levels"))}
 
-    if args.check and rank == 0:
+    if args.check and sharded is not None:
+        import oracle
+        Lsx = sharded.gather_factor()
+        if rank == 0:
+            res, _ = oracle.chol_residual(sym, Lsx)
+            out["config"]["residual"] = res
+        del Lsx
+    elif args.check and rank == 0:
         import oracle
         Lsx = plan.get_factor()
         res, _ = (oracle.lu_residual if lu else oracle.chol_residual)(sym, Lsx)
@@ -179,7 +205,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    plan.close()
+    if sharded is not None:
+        sharded.close()
+    else:
+        plan.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -118,6 +118,24 @@ double sf_chol_plan_stat(const sf_chol_plan *plan, const char *name);
 int sf_chol_plan_set_profiling(sf_chol_plan *plan, int on);
 int sf_chol_plan_destroy(sf_chol_plan *plan);
 
+/* ---- multi-GPU sharding of ONE factorization by elimination-tree subtrees (the reference has no
+ * inter-GPU path: its handlers exchange panels through host memory, C:2267, C:2421-2467).
+ * sf_subtree_partition: owner[s] = rank whose subtree holds supernode s, or -1 for the replicated top supernodes.
+ * Rank r then builds a plan with phase[s] = 0 (owner[s] == r), 1 (owner[s] == -1), -1 (otherwise) and runs
+ *     sf_chol_plan_factorize_phase(plan, 0)   assemble + own subtrees; their updates of top panels accumulate locally
+ *     all-reduce(sum) of sf_chol_plan_top_region over the ranks (RCCL)   -- the one exchange step
+ *     sf_chol_plan_factorize_phase(plan, 1)   top supernodes, replicated on every rank
+ * load_top != 0 on exactly ONE rank (it contributes the matrix entries of the top panels to the sum). ---- */
+int sf_subtree_partition(sf_long nsuper, const sf_long *Super, const sf_long *SuperMap, const sf_long *Lsip,
+                         const sf_long *Lsi, int nranks, int32_t *owner, double *top_fraction, double *max_load_fraction);
+int sf_chol_plan_create_sharded(sf_chol_plan **plan, int device, sf_long n, sf_long nsuper,
+                                const sf_long *Super, const sf_long *SuperMap,
+                                const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                                const sf_long *Lp, const sf_long *Li, const int32_t *phase, int load_top);
+int sf_chol_plan_factorize_phase(sf_chol_plan *plan, int phase /* 0, 1, or -1 = both */, int sync);
+/* device pointer and length (doubles) of the contiguous region holding every top panel */
+int sf_chol_plan_top_region(sf_chol_plan *plan, void **device_ptr, sf_long *count);
+
 /* ---- device plan for supernodal no-pivot LU (replaces L:2668-3573 + LU/Source/cuda_kernel.cu:22-176).
  * Symbolic arrays from sf_symbolic_create_lu; Lsxp is the reference's (packed (2*nsrow-nscol) x nscol) offsets.
  * Up/Ui = U by row; pass NULL for both when the input is symmetric (U aliases L, L:2718-2729).

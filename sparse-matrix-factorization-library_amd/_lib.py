@@ -15,6 +15,23 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C sparse-matrix-factorization-library_amd/csrc`). There is no Python/CPU fallback.")
 
+# One HIP runtime per process: PyTorch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  If this
+# library pulled in the system runtime first and torch then loaded its bundled copy, the second runtime would see
+# no device.  So when torch is installed, its runtime is loaded first (without importing torch) and both share it.
+def _preload_torch_hip_runtime():
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+_preload_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 LU_LIB_PATH = os.path.join(_HERE, "libsparseframe_lu_hip.so")
 if not os.path.exists(LU_LIB_PATH):
@@ -70,6 +87,15 @@ lib.sf_chol_plan_set_profiling.restype = C.c_int
 lib.sf_chol_plan_destroy.argtypes = [C.c_void_p]
 lib.sf_chol_plan_destroy.restype = C.c_int
 
+lib.sf_subtree_partition.argtypes = [C.c_int64, c_long_p, c_long_p, c_long_p, c_long_p, C.c_int, C.POINTER(C.c_int32),
+                                     c_double_p, c_double_p]
+lib.sf_subtree_partition.restype = C.c_int
+lib.sf_chol_plan_create_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7 + [C.POINTER(C.c_int32), C.c_int]
+lib.sf_chol_plan_create_sharded.restype = C.c_int
+lib.sf_chol_plan_factorize_phase.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.sf_chol_plan_factorize_phase.restype = C.c_int
+lib.sf_chol_plan_top_region.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), c_long_p]
+lib.sf_chol_plan_top_region.restype = C.c_int
 lib.sf_lu_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9
 lib.sf_lu_plan_create.restype = C.c_int
 lib.sf_lu_plan_set_values.argtypes = [C.c_void_p, c_double_p, c_double_p]

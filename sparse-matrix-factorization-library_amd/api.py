@@ -127,14 +127,38 @@ def analyze(n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU, method=
     return Symbolic(n, Cp, Ci, Cx, perm, dev_slot_size, method, symmetric)
 
 
-class CholPlan:
-    """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present."""
+def subtree_partition(sym, nranks):
+    """owner[s] = rank of the elimination-tree subtree holding supernode s, -1 for the replicated top supernodes.
+    Returns (owner int32[nsuper], top flop fraction, heaviest rank's subtree flop fraction)."""
+    owner = np.empty(max(sym.nsuper, 1), dtype=np.int32)
+    tf, ml = C.c_double(), C.c_double()
+    check(lib.sf_subtree_partition(sym.nsuper, _lp(sym.Super), _lp(sym.SuperMap), _lp(sym.Lsip), _lp(sym.Lsi), nranks,
+                                   owner.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(tf), C.byref(ml)),
+          "sf_subtree_partition")
+    return owner[:sym.nsuper], tf.value, ml.value
 
-    def __init__(self, sym, device=0):
+
+def phases_for_rank(owner, rank):
+    """phase array of sf_chol_plan_create_sharded for `rank`: 0 own subtree, 1 top (replicated), -1 elsewhere"""
+    return np.where(owner == rank, 0, np.where(owner < 0, 1, -1)).astype(np.int32)
+
+
+class CholPlan:
+    """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present.
+    phase/load_top: multi-GPU sharding (sf_chol_plan_create_sharded); default = the whole matrix on one device."""
+
+    def __init__(self, sym, device=0, phase=None, load_top=True):
         h = C.c_void_p()
         self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
-        check(lib.sf_chol_plan_create(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep]),
-              "sf_chol_plan_create")
+        if phase is None:
+            check(lib.sf_chol_plan_create(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep]),
+                  "sf_chol_plan_create")
+        else:
+            phase = np.ascontiguousarray(phase, dtype=np.int32)
+            check(lib.sf_chol_plan_create_sharded(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
+                                                  phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0),
+                  "sf_chol_plan_create_sharded")
+        self.device = device
         self._h = h
         self.xsize = sym.xsize
         self.n = sym.n
@@ -146,11 +170,22 @@ class CholPlan:
     def factorize(self, sync=True):
         check(lib.sf_chol_plan_factorize(self._h, 1 if sync else 0), "sf_chol_plan_factorize")
 
+    def factorize_phase(self, which, sync=True):
+        check(lib.sf_chol_plan_factorize_phase(self._h, which, 1 if sync else 0), "sf_chol_plan_factorize_phase")
+
+    def top_region(self):
+        """(device pointer, number of doubles) of the contiguous top-panel region"""
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        check(lib.sf_chol_plan_top_region(self._h, C.byref(ptr), C.byref(cnt)), "sf_chol_plan_top_region")
+        return ptr.value or 0, cnt.value
+
     def sync(self):
         check(lib.sf_chol_plan_sync(self._h), "sf_chol_plan_sync")
 
-    def get_factor(self):
-        out = np.empty(max(self.xsize, 1), dtype=np.float64)
+    def get_factor(self, out=None):
+        """D2H in the reference layout; a sharded plan fills only the panels stored on this rank"""
+        if out is None:
+            out = np.zeros(max(self.xsize, 1), dtype=np.float64)
         check(lib.sf_chol_plan_get_factor(self._h, _dp(out)), "sf_chol_plan_get_factor")
         return out[:self.xsize]
 

@@ -75,6 +75,13 @@ struct sf_chol_plan {
     int64_t* d_Xp = nullptr;    // LU: offsets of the nsrow x nscol panels (the reference's Lsxp has the packed sizes)
     double* d_pack = nullptr;   // LU: staging buffer in the reference layout for the download
     bool u_alias = false;       // LU with a symmetric input: U aliases L (reference L:2718-2729)
+    // multi-GPU sharding: phase[s] = 0 owned subtree supernode, 1 top supernode (replicated), -1 not on this rank
+    std::vector<int8_t> phase;
+    std::vector<int64_t> h_XP;  // device panel offsets (doubles), -1 when the panel is not stored on this rank
+    bool partial = false;       // some supernodes are absent or the top panels are not loaded here
+    int64_t top_off = 0, top_size = 0;   // contiguous region of the top panels inside one panel set
+    size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
+    int8_t* d_loadmask = nullptr;
     int device = 0;
     int64_t n = 0, nsuper = 0, nnz = 0, isize = 0, xsize = 0;
     hipStream_t stream = nullptr;
@@ -147,7 +154,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -170,7 +177,8 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
 static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_long nsuper,
                        const sf_long* Super, const sf_long* SuperMap,
                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
-                       const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui) {
+                       const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
+                       const int32_t* phase_in = nullptr, int load_top = 1) {
     if (!out) return SF_ERR_ARG;
     *out = nullptr;
     if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
@@ -194,10 +202,31 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     p->xsize = Lsxp[nsuper];
     p->u_alias = lu && (!Up || !Ui);
     p->unz = (lu && !p->u_alias) ? Up[n] : 0;
-    // offsets of the nsrow x nscol panels
-    std::vector<int64_t> XP(nsuper + 1, 0);
-    for (sf_long s = 0; s < nsuper; ++s) XP[s + 1] = XP[s] + (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
-    p->xC = XP[nsuper];
+    // Device offsets of the nsrow x nscol panels: the owned (phase 0) panels in supernode order, then the top
+    // (phase 1) panels, contiguous, so that the multi-GPU merge is ONE all-reduce over [top_off, top_off+top_size).
+    // With no phase array every supernode is phase 0 and the layout is the reference's Lsxp (Cholesky).
+    p->phase.assign(nsuper, 0);
+    if (phase_in)
+        for (sf_long s = 0; s < nsuper; ++s) {
+            if (phase_in[s] < -1 || phase_in[s] > 1) { delete p; return SF_ERR_ARG; }
+            p->phase[s] = (int8_t)phase_in[s];
+        }
+    std::vector<int64_t> XP(nsuper + 1, -1);
+    {
+        int64_t run = 0;
+        for (int ph = 0; ph < 2; ++ph) {
+            if (ph == 1) p->top_off = run;
+            for (sf_long s = 0; s < nsuper; ++s)
+                if (p->phase[s] == ph) { XP[s] = run; run += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]); }
+        }
+        p->top_size = run - p->top_off;
+        p->xC = run;
+        XP[nsuper] = run;
+    }
+    p->h_XP = XP;
+    for (sf_long s = 0; s < nsuper; ++s)
+        if (p->phase[s] != 0) p->partial = true;
+    if (!load_top) p->partial = true;
     const int64_t ushift = p->xC;     // PU(s) = PL(s) + ushift
 
     // ---------------- validate the structure the kernels index with ----------------
@@ -230,8 +259,16 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     }
     p->nlevels = nlevels;
     p->level_of = level;
-    std::vector<std::vector<sf_long>> by_level(nlevels);
-    for (sf_long s = 0; s < nsuper; ++s) by_level[level[s]].push_back(s);
+    // sharding consistency: every row of a stored supernode must belong to a stored supernode (its updates have
+    // a local target), and a top supernode only has top ancestors
+    for (sf_long s = 0; s < nsuper; ++s) {
+        if (p->phase[s] < 0) continue;
+        const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        for (sf_long k = nscol; k < nsrow; ++k) {
+            const int8_t pa = p->phase[SuperMap[Lsi[Lsip[s] + k]]];
+            if (pa < 0 || (p->phase[s] == 1 && pa != 1)) { delete p; return SF_ERR_ARG; }
+        }
+    }
 
     // ---------------- task tables ----------------
     std::vector<PotrfTask> potrf;
@@ -255,8 +292,14 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     }
     };
 
+    for (int ph = 0; ph < 2; ++ph) {
+    if (ph == 1) p->launch_split = p->launches.size();
+    std::vector<std::vector<sf_long>> by_level(nlevels);
+    for (sf_long s = 0; s < nsuper; ++s)
+        if (p->phase[s] == ph) by_level[level[s]].push_back(s);
     for (int l = 0; l < nlevels; ++l) {
         const std::vector<sf_long>& Sl = by_level[l];
+        if (Sl.empty()) continue;
         sf_long maxcol = 0;
         for (sf_long s : Sl) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
         // Two-level blocking of the in-panel factorization.  Outer block columns of OUTER_NB columns are
@@ -382,6 +425,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{3, g0, (int)(gtasks.size() - g0)});
     }
+    }   // phases
     p->n_gemm_tasks = (int64_t)gtasks.size();
 
     // K-step prefix of every GEMM launch (stream-K work distribution, see k_gemm)
@@ -431,8 +475,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
         if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
-        if (lu) {
+        if (lu || p->partial) {
             if ((rc = upload(&p->d_Xp, XP, &p->bytes_device))) break;
+        }
+        if (p->partial) {
+            std::vector<int8_t> mask(std::max<sf_long>(nsuper, 1), 0);
+            for (sf_long s = 0; s < nsuper; ++s) mask[s] = (p->phase[s] == 0 || (p->phase[s] == 1 && load_top)) ? 1 : 0;
+            if ((rc = upload(&p->d_loadmask, mask, &p->bytes_device))) break;
+        }
+        if (lu) {
             if (!p->u_alias) {
                 if ((rc = upload(&p->d_Up, Up64, &p->bytes_device))) break;
                 if ((rc = upload(&p->d_Ui, Ui32, &p->bytes_device))) break;
@@ -456,6 +507,13 @@ int sf_chol_plan_create(sf_chol_plan** out, int device, sf_long n, sf_long nsupe
                         const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                         const sf_long* Lp, const sf_long* Li) {
     return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr);
+}
+
+int sf_chol_plan_create_sharded(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
+                                const sf_long* Super, const sf_long* SuperMap,
+                                const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                                const sf_long* Lp, const sf_long* Li, const int32_t* phase, int load_top) {
+    return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, phase, load_top);
 }
 
 int sf_lu_plan_create(sf_lu_plan** out, int device, sf_long n, sf_long nsuper,
@@ -496,8 +554,9 @@ int sf_chol_plan_sync(sf_chol_plan* p) {
     return p->last_status;
 }
 
-int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
-    if (!p) return SF_ERR_ARG;
+// phase 0: assemble + owned subtrees; phase 1: top supernodes; -1: both (single-GPU path)
+int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
+    if (!p || which < -1 || which > 1) return SF_ERR_ARG;
     if (!p->values_set) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
@@ -507,28 +566,34 @@ int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
         hipEvent_t e;
         if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); evs.push_back(e); }
     };
-
-    HIP_TRY(hipEventRecord(p->ev0, st));
-    HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), st));
-    if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
-    if (!p->lu) {
-        sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                               p->d_Lsi, p->d_Lsxp, p->d_Lsx, 0, st);
-    } else {
-        // L panel: strictly lower entries of the columns of L; U^T panel: row j of U (diagonal included) goes to
-        // column j of PU at the positions of its column indices (reference loadA, L:2490-2533)
-        sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                               p->d_Lsi, p->d_Xp, p->d_Lsx, 1, st);
-        if (p->u_alias)
+    const bool first = (which != 1);
+    if (first) HIP_TRY(hipEventRecord(p->ev0, st));
+    if (first) {
+        HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), st));
+        if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
+        const int64_t* xp = (p->lu || p->partial) ? p->d_Xp : p->d_Lsxp;
+        if (!p->lu) {
             sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                                   p->d_Lsi, p->d_Xp, p->d_Lsx + p->xC, 0, st);
-        else
-            sf::launch_load_panels(p->d_Up, p->d_Ui, p->d_Ux, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                                   p->d_Lsi, p->d_Xp, p->d_Lsx + p->xC, 0, st);
+                                   p->d_Lsi, xp, p->d_Lsx, 0, p->d_loadmask, st);
+        } else {
+            // L panel: strictly lower entries of the columns of L; U^T panel: row j of U (diagonal included) goes to
+            // column j of PU at the positions of its column indices (reference loadA, L:2490-2533)
+            sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                                   p->d_Lsi, xp, p->d_Lsx, 1, p->d_loadmask, st);
+            if (p->u_alias)
+                sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                                       p->d_Lsi, xp, p->d_Lsx + p->xC, 0, p->d_loadmask, st);
+            else
+                sf::launch_load_panels(p->d_Up, p->d_Ui, p->d_Ux, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
+                                       p->d_Lsi, xp, p->d_Lsx + p->xC, 0, p->d_loadmask, st);
+        }
     }
     mark();
     std::vector<int> kinds;
-    for (const Launch& L : p->launches) {
+    const size_t l0 = (which == 1) ? p->launch_split : 0;
+    const size_t l1 = (which == 0) ? p->launch_split : p->launches.size();
+    for (size_t li = l0; li < l1; ++li) {
+        const Launch& L = p->launches[li];
         switch (L.kind) {
             case 0:
                 if (p->lu) sf::launch_getrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->xC, p->d_info, st);
@@ -541,14 +606,16 @@ int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
         }
         if (p->profiling) { kinds.push_back(L.kind); mark(); }
     }
-    HIP_TRY(hipEventRecord(p->ev1, st));
+    if (which != 0) HIP_TRY(hipEventRecord(p->ev1, st));
     HIP_TRY(hipGetLastError());
     if (p->profiling) {
         HIP_TRY(hipStreamSynchronize(st));
-        p->last_load_ms = p->last_panel_ms = p->last_update_ms = 0;
-        for (double& v : p->last_kind_ms) v = 0;
+        if (first) {
+            p->last_load_ms = p->last_panel_ms = p->last_update_ms = 0;
+            for (double& v : p->last_kind_ms) v = 0;
+        }
         float ms = 0;
-        if (!evs.empty() && hipEventElapsedTime(&ms, p->ev0, evs[0]) == hipSuccess) p->last_load_ms = ms;
+        if (first && !evs.empty() && hipEventElapsedTime(&ms, p->ev0, evs[0]) == hipSuccess) p->last_load_ms = ms;
         for (size_t k = 0; k + 1 < evs.size(); ++k) {
             if (hipEventElapsedTime(&ms, evs[k], evs[k + 1]) != hipSuccess) continue;
             if (kinds[k] == 3) p->last_update_ms += ms; else p->last_panel_ms += ms;
@@ -556,7 +623,19 @@ int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
         }
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
-    if (sync) return sf_chol_plan_sync(p);
+    if (sync) {
+        if (which == 0) { HIP_TRY(hipStreamSynchronize(st)); return SF_OK; }
+        return sf_chol_plan_sync(p);
+    }
+    return SF_OK;
+}
+
+int sf_chol_plan_factorize(sf_chol_plan* p, int sync) { return sf_chol_plan_factorize_phase(p, -1, sync); }
+
+int sf_chol_plan_top_region(sf_chol_plan* p, void** dptr, sf_long* count) {
+    if (!p || !dptr || !count) return SF_ERR_ARG;
+    *dptr = (void*)(p->d_Lsx + p->top_off);
+    *count = p->top_size;
     return SF_OK;
 }
 
@@ -565,10 +644,28 @@ int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->xsize <= 0) return SF_OK;
-    if (!p->lu) {
+    if (!p->lu && !p->partial) {
         HIP_TRY(hipMemcpy(Lsx, p->d_Lsx, p->xsize * sizeof(double), hipMemcpyDeviceToHost));
         return SF_OK;
     }
+    if (!p->lu) {
+        // sharded plan: copy the panels stored here to their reference positions, one copy per run of
+        // supernodes that is contiguous in both layouts; panels of other ranks are left untouched
+        sf_long s = 0;
+        while (s < p->nsuper) {
+            if (p->h_XP[s] < 0) { ++s; continue; }
+            sf_long e = s;
+            int64_t len = 0;
+            while (e < p->nsuper && p->h_XP[e] == p->h_XP[s] + len) {
+                len += p->h_Lsxp[e + 1] - p->h_Lsxp[e];
+                ++e;
+            }
+            HIP_TRY(hipMemcpy(Lsx + p->h_Lsxp[s], p->d_Lsx + p->h_XP[s], len * sizeof(double), hipMemcpyDeviceToHost));
+            s = e;
+        }
+        return SF_OK;
+    }
+    if (p->partial) return SF_ERR_ARG;   // sharded LU download: not built
     if (!p->d_pack) {
         HIP_TRY(hipMalloc((void**)&p->d_pack, p->xsize * sizeof(double)));
         p->bytes_device += p->xsize * sizeof(double);
@@ -600,6 +697,8 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     if (!p || !name) return -1;
     const std::string k(name);
     if (k == "levels") return p->nlevels;
+    if (k == "top_doubles") return (double)p->top_size;
+    if (k == "stored_doubles") return (double)p->xC;
     if (k == "launches") return (double)p->launches.size();
     if (k == "gemm_tasks") return (double)p->n_gemm_tasks;
     if (k == "update_pairs") return (double)p->n_pairs;

@@ -169,6 +169,12 @@ double sf_symbolic_flops(const sf_symbolic* sym, int which) {
     return 0;
 }
 
+int sf_subtree_partition(sf_long nsuper, const sf_long* Super, const sf_long* SuperMap, const sf_long* Lsip,
+                         const sf_long* Lsi, int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction) {
+    if (!Super || !Lsip || (nsuper > 0 && (!SuperMap || !Lsi))) return SF_ERR_ARG;
+    return sf::subtree_partition(nsuper, Super, SuperMap, Lsip, Lsi, nranks, owner, top_fraction, max_load_fraction) ? SF_ERR_ARG : SF_OK;
+}
+
 int sf_grid_nd_perm(sf_long nx, sf_long ny, sf_long nz, sf_long leaf, sf_long sep_width, sf_long* perm) {
     return sf::grid_nd_perm(nx, ny, nz, leaf, sep_width, perm) ? SF_ERR_ARG : SF_OK;
 }

@@ -55,7 +55,7 @@ struct TrsmTask {   // rows [row0, row0+nrows) of panel columns [diag, diag+b) <
 // skip_diag != 0: entries with row == column are not stored (LU: the L panel)
 void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
                         const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
-                        const int64_t* Lsxp, double* Lsx, int skip_diag, hipStream_t st);
+                        const int64_t* Lsxp, double* Lsx, int skip_diag, const int8_t* load_mask, hipStream_t st);
 void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st);
 // LU: the diagonal block is split over two panels, L (strictly lower, at Lsx + task.panel) and U^T (lower
 // including the diagonal, at Lsx + task.panel + u_shift)

@@ -37,10 +37,12 @@ __global__ void __launch_bounds__(256)
 k_load_panels(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, const double* __restrict__ Lx, int32_t n,
               const int32_t* __restrict__ Super, const int32_t* __restrict__ SuperMap,
               const int64_t* __restrict__ Lsip, const int32_t* __restrict__ Lsi,
-              const int64_t* __restrict__ Lsxp, double* __restrict__ Lsx, int skip_diag) {
+              const int64_t* __restrict__ Lsxp, double* __restrict__ Lsx, int skip_diag,
+              const int8_t* __restrict__ load_mask) {
     const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int32_t s = SuperMap[j];
+    if (load_mask && !load_mask[s]) return;     // multi-GPU: panel not stored here, or loaded by another rank
     const int32_t c0 = Super[s], c1 = Super[s + 1];
     const int64_t r0 = Lsip[s];
     const int32_t nsrow = (int32_t)(Lsip[s + 1] - r0);
@@ -57,10 +59,10 @@ k_load_panels(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, co
 
 void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
                         const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
-                        const int64_t* Lsxp, double* Lsx, int skip_diag, hipStream_t st) {
+                        const int64_t* Lsxp, double* Lsx, int skip_diag, const int8_t* load_mask, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_load_panels, dim3((n + 255) / 256), dim3(256), 0, st,
-                       Lp, Li, Lx, n, Super, SuperMap, Lsip, Lsi, Lsxp, Lsx, skip_diag);
+                       Lp, Li, Lx, n, Super, SuperMap, Lsip, Lsi, Lsxp, Lsx, skip_diag, load_mask);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -555,6 +555,96 @@ double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems
 }
 
 // ---------------------------------------------------------------------------------------------
+// Subtree-to-rank mapping for multi-GPU sharding.  The supernodal tree is cut from the roots down:
+// the heaviest remaining subtree is split (its root joins the replicated "top" set, its children become
+// subtrees) while that lowers the estimate  t = flops(top) + max_rank(sum of its subtrees' flops)  with the
+// subtrees placed longest-first on the least loaded rank.  owner[s] = rank of the subtree holding s, or -1 (top).
+// Work of a supernode = its own factorization + every update it pushes to its ancestors (right-looking).
+// ---------------------------------------------------------------------------------------------
+int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi,
+                      int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction) {
+    if (nsuper < 0 || nranks < 1 || !owner) return 1;
+    std::vector<Long> par(nsuper, -1);
+    std::vector<double> fl(nsuper, 0.0), sub(nsuper, 0.0);
+    std::vector<std::vector<Long>> kids(nsuper);
+    double total = 0;
+    for (Long s = 0; s < nsuper; ++s) {
+        const double k = (double)(Super[s + 1] - Super[s]);
+        const Long nsrow = Lsip[s + 1] - Lsip[s];
+        const double m = (double)nsrow - k;
+        double f = k * k * k / 3.0 + m * k * k;
+        const Long* rows = Lsi + Lsip[s];
+        Long i = (Long)k;
+        if (i < nsrow) par[s] = SuperMap[rows[i]];
+        while (i < nsrow) {
+            const Long o = SuperMap[rows[i]];
+            Long e = i;
+            while (e < nsrow && SuperMap[rows[e]] == o) ++e;
+            const double dn = (double)(e - i), dm = (double)(nsrow - e);
+            f += dn * (dn + 1) * k + 2.0 * dm * dn * k;
+            i = e;
+        }
+        fl[s] = f;
+        total += f;
+    }
+    for (Long s = 0; s < nsuper; ++s) {
+        sub[s] += fl[s];
+        if (par[s] >= 0) { sub[par[s]] += sub[s]; kids[par[s]].push_back(s); }
+    }
+    std::vector<Long> roots;            // current subtree roots
+    for (Long s = 0; s < nsuper; ++s)
+        if (par[s] < 0) roots.push_back(s);
+    std::vector<char> is_top(nsuper, 0);
+    double top = 0;
+    auto estimate = [&](const std::vector<Long>& rs, std::vector<int>* assign) {
+        std::vector<Long> order(rs);
+        std::sort(order.begin(), order.end(), [&](Long a, Long b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
+        std::vector<double> load(nranks, 0.0);
+        if (assign) assign->assign(nsuper, -1);
+        for (Long r : order) {
+            int best = 0;
+            for (int q = 1; q < nranks; ++q)
+                if (load[q] < load[best]) best = q;
+            load[best] += sub[r];
+            if (assign) (*assign)[r] = best;
+        }
+        return *std::max_element(load.begin(), load.end());
+    };
+    std::vector<Long> best_roots = roots;
+    std::vector<char> best_top = is_top;
+    double best_t = top + estimate(roots, nullptr), best_topf = top;
+    int stale = 0;
+    while (nranks > 1 && stale < 4 * nranks) {
+        // split the heaviest subtree that has children
+        Long pick = -1;
+        size_t pos = 0;
+        for (size_t k = 0; k < roots.size(); ++k)
+            if (!kids[roots[k]].empty() && (pick < 0 || sub[roots[k]] > sub[pick])) { pick = roots[k]; pos = k; }
+        if (pick < 0) break;
+        roots.erase(roots.begin() + pos);
+        is_top[pick] = 1;
+        top += fl[pick];
+        for (Long c : kids[pick]) roots.push_back(c);
+        const double t = top + estimate(roots, nullptr);
+        if (t < best_t * (1.0 - 1e-12)) { best_t = t; best_roots = roots; best_top = is_top; best_topf = top; stale = 0; }
+        else ++stale;
+    }
+    std::vector<int> assign;
+    const double maxload = estimate(best_roots, &assign);
+    // propagate the owner of each subtree root to its descendants (children precede parents in the postorder)
+    std::vector<int32_t> own(nsuper, -1);
+    for (Long s = nsuper - 1; s >= 0; --s) {
+        if (best_top[s]) { own[s] = -1; continue; }
+        if (assign[s] >= 0) own[s] = assign[s];
+        else own[s] = (par[s] >= 0) ? own[par[s]] : 0;
+    }
+    for (Long s = 0; s < nsuper; ++s) owner[s] = own[s];
+    if (top_fraction) *top_fraction = total > 0 ? best_topf / total : 0;
+    if (max_load_fraction) *max_load_fraction = total > 0 ? maxload / total : 0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // geometric nested dissection on a regular grid
 // ---------------------------------------------------------------------------------------------
 namespace {

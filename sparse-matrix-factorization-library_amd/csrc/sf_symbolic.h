@@ -55,6 +55,9 @@ int analyze_lu(Long n, const Long* Cp, const Long* Ci, const double* Cx,
 double flops_struct(const Symbolic& S);
 double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems);
 
+int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi,
+                      int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction);
+
 int grid_nd_perm(Long nx, Long ny, Long nz, Long leaf, Long sepw, Long* perm);
 
 }  // namespace sf

@@ -156,3 +156,44 @@ def test_large_properties_64cubed(oracle):
     x2 = oracle.chol_solve(sym, Lsx, 2 * b)
     assert np.allclose(x2, 2 * x, rtol=1e-13, atol=0)
     plan.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_plans_emulated_ranks_on_one_gpu(oracle, world):
+    """the multi-GPU sharding with all ranks' plans built on the single test GPU: phase 0 on every
+    rank, the top regions summed through torch tensors aliasing the plans' device memory (what the RCCL
+    all-reduce does between GPUs), phase 1 on every rank, partial downloads merged on the host."""
+    import torch
+    from importlib import import_module
+    sharded = import_module("sparse-matrix-factorization-library_amd.sharded")
+    N = 20
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 1 << 30)
+    owner, tf, ml = sf.subtree_partition(sym, world)
+    assert (owner < 0).any()
+    engines = [sharded.HipEngine(sym, sf.phases_for_rank(owner, r), r == 0, 0) for r in range(world)]
+    for rep in range(2):                                   # plans are reusable
+        for e in engines:
+            e.set_values(sym.Lx)
+            e.factorize_phase(0)
+        tops = [e.top_tensor() for e in engines]
+        assert tops[0].is_cuda and tops[0].dtype == torch.float64 and tops[0].numel() == engines[0].plan.top_region()[1]
+        total = tops[0].clone()
+        for t in tops[1:]:
+            total += t
+        for t in tops:
+            t.copy_(total)
+        torch.cuda.synchronize()
+        for e in engines:
+            e.factorize_phase(1)
+        full = np.zeros(sym.xsize)
+        for e in engines:
+            e.get_factor(full)
+        ref, info, _ = oracle.chol_factorize(sym)
+        assert rel_err(full, ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+        res, _ = oracle.chol_residual(sym, full)
+        assert res <= TOL_RESIDUAL
+    stored = [e.plan.stat("stored_doubles") for e in engines]
+    assert max(stored) < sym.xsize                          # compact per-rank storage
+    for e in engines:
+        e.close()
