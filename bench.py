@@ -54,10 +54,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (never set by the driver): SF_BENCH_BACKEND=gloo SF_BENCH_DEVICE=0 lets several ranks share
+    # the single GPU of a test box to exercise the N > 1 code path end to end (gloo stages CUDA tensors via the host)
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    if "SF_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SF_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     ngpu = max(args.gpus, 1)
     if world != ngpu and world > 1:
         raise SystemExit(f"--gpus {ngpu} but WORLD_SIZE={world}")
