@@ -41,6 +41,9 @@ def main():
                     help="cholesky: 3-D 7-pt Laplacian (the headline workload); lu: unsymmetric 19-pt stencil, no-pivot LU")
     ap.add_argument("--cpu-grid", type=int, default=72, help="N of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="BLAS threads of the CPU baseline (0 = min(cores,16))")
+    ap.add_argument("--workload", choices=["lap3d", "stencil2d"], default="lap3d",
+                    help="cholesky only: lap3d = N^3 7-point Laplacian (config 2); stencil2d = N x N grid, 21-point random SPD "
+                         "stencil, 2-line separators (BASELINE config 3 at N = 1000)")
     ap.add_argument("--mp", choices=["subtree", "replicas"], default="subtree",
                     help="N > 1: shard one matrix by elimination-tree subtrees (default) or run one matrix per GPU")
     ap.add_argument("--check", action="store_true", help="download the factor and check the residual on the host")
@@ -75,13 +78,16 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the numeric path has no CPU fallback")
 
     lu = args.method == "lu"
-    N = args.grid or (79 if lu else 128)
+    N = args.grid or (79 if lu else (1000 if args.workload == "stencil2d" else 128))
     t0 = time.time()
 
     def make(M):
         if lu:   # BASELINE config 5 stand-in: n ~ 500k, nnz ~ 9M, structurally and numerically unsymmetric, diagonally dominant
             n_, Cp_, Ci_, Cx_ = sf.gen.unsymmetric_stencil(M, M, M, extra_per_row=0, seed=2024, drop=0.05)
             return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False), len(Ci_)
+        if args.workload == "stencil2d":
+            n_, Cp_, Ci_, Cx_ = sf.gen.stencil_spd_lower(M, M)
+            return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, 1, 3, 2), sf.REFERENCE_SLOT_1GPU), len(Ci_)
         n_, Cp_, Ci_, Cx_ = sf.gen.laplacian_lower(M, M, M)
         return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU), len(Ci_)
 
@@ -139,6 +145,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"unsymmetric 3D 19-point stencil {N}^3 (5% of entries dropped one-sidedly), diagonally dominant, "
                                 f"no-pivot LU fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if lu else
+                               (f"2D {N}x{N} grid, 21-point random SPD stencil (rng 12345), Cholesky fp64, geometric ND with 2-line "
+                                f"separators, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if args.workload == "stencil2d" else
                                f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
                    "n": n, "nnz_input": int(nnz_in), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
                    "F_struct": F_struct, "F_exec": F_exec,
@@ -159,7 +167,7 @@ def main():
         # HBM traffic of that kernel: not measurable live (PMC counters need rocprofv3); taken from the committed
         # PMC passes of this exact workload when they exist (profiles/*_pmc_traffic_128cubed.json, bytes per launch)
         traffic = None
-        if N == 128 and not lu:
+        if N == 128 and not lu and args.workload == "lap3d":
             import glob
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_128cubed.json")))
             if files:
@@ -198,14 +206,14 @@ def main():
         import oracle
         threads = args.cpu_threads or min(os.cpu_count() or 1, 16)   # reference: min(omp_max, 16), SparseFrame.c:3357
         binfo = oracle.blas_init("auto", threads=threads)
-        M = min(args.cpu_grid, 56) if lu else args.cpu_grid
+        M = min(args.cpu_grid, 56) if lu else (N if args.workload == "stencil2d" else args.cpu_grid)
         n2, sym2, _ = make(M)
         cpu_factorize = oracle.lu_factorize if lu else oracle.chol_factorize
         cpu_factorize(sym2)   # warm-up: first-touch page faults dominated the reference probe
         _, info, st = cpu_factorize(sym2)
         out["cpu_baseline"] = {"value": round(sym2.flops_struct / st["seconds"] / 1e9, 2), "unit": "GFLOP/s",
                                "cores": int(binfo["threads"]), "kind": "port",
-                               "sample": f"{'unsymmetric 19-point stencil' if lu else '3D 7-point Laplacian'} {M}^3 (same generator and ordering), full numeric "
+                               "sample": f"{'unsymmetric 19-point stencil' if lu else ('2D 21-point stencil' if args.workload == 'stencil2d' else '3D 7-point Laplacian')} grid {M} (same generator and ordering), full numeric "
                                          f"factorization, F_struct {sym2.flops_struct:.3e}, {st['seconds']:.2f} s, "
                                          f"1 tree worker x {binfo['threads']} BLAS threads, "
                                          f"{os.path.basename(binfo['name'])}",
