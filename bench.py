@@ -188,6 +188,13 @@ def main():
                            "flops_update": plan.stat("flops_update"),
                            "launches": int(plan.stat("launches")), "levels": int(plan.stat("levels"))}
 
+    if rank == 0 and sharded is None and not lu:
+        # device-side solve with the resident factor + the reference's validate() residual on the host (numpy);
+        # no oracle code and no 30 GB download involved
+        xs = plan.solve(1 + np.arange(n) / n)
+        out["config"]["residual_device_solve"] = sf.validate_solution(sym, xs)
+        out["config"]["device_solve_ms"] = round(plan.stat("last_solve_ms"), 3)
+
     if args.check and sharded is not None:
         import oracle
         Lsx = sharded.gather_factor()

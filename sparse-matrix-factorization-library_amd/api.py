@@ -127,6 +127,25 @@ def analyze(n, Cp, Ci, Cx, perm=None, dev_slot_size=REFERENCE_SLOT_1GPU, method=
     return Symbolic(n, Cp, Ci, Cx, perm, dev_slot_size, method, symmetric)
 
 
+def validate_solution(sym, x, b=None):
+    """the reference's SparseFrame_validate residual (SparseFrame.c:3182-3263) for a given solution x of the permuted
+    system: b_i = 1 + i/n, r = A x - b with the stored triangle used symmetrically,
+    |r|_inf / (|A|_1 |x|_inf + |b|_inf).  Vectorised numpy (host check of a device solve)."""
+    n = sym.n
+    if b is None:
+        b = 1 + np.arange(n) / n
+    Lp, Li, Lx = sym.Lp, sym.Li, sym.Lx
+    cols = np.repeat(np.arange(n), np.diff(Lp))
+    r = -np.asarray(b, dtype=np.float64).copy()
+    np.add.at(r, Li, Lx * x[cols])
+    off = Li != cols
+    np.add.at(r, cols[off], Lx[off] * x[Li[off]])
+    colsum = np.zeros(n)
+    np.add.at(colsum, cols, np.abs(Lx))
+    np.add.at(colsum, Li[off], np.abs(Lx[off]))
+    return float(np.abs(r).max() / (colsum.max() * np.abs(x).max() + np.abs(b).max()))
+
+
 def subtree_partition(sym, nranks):
     """owner[s] = rank of the elimination-tree subtree holding supernode s, -1 for the replicated top supernodes.
     Returns (owner int32[nsuper], top flop fraction, heaviest rank's subtree flop fraction)."""

@@ -82,6 +82,12 @@ struct sf_chol_plan {
     int64_t top_off = 0, top_size = 0;   // contiguous region of the top panels inside one panel set
     size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
     int8_t* d_loadmask = nullptr;
+    // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
+    sf::SolveTask* d_solve = nullptr;
+    double* d_x = nullptr;
+    struct SolveStep { int64_t diag_first; int diag_count; int64_t fwd_first; int fwd_count; int64_t bwd_first; int bwd_count; };
+    std::vector<SolveStep> solve_steps;
+    double last_solve_ms = 0;
     int device = 0;
     int64_t n = 0, nsuper = 0, nnz = 0, isize = 0, xsize = 0;
     hipStream_t stream = nullptr;
@@ -154,7 +160,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -428,6 +434,41 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     }   // phases
     p->n_gemm_tasks = (int64_t)gtasks.size();
 
+    // ---------------- device solve schedule (Cholesky, unsharded) ----------------
+    std::vector<sf::SolveTask> solve;
+    if (!lu && !p->partial) {
+        std::vector<std::vector<sf_long>> by_level(nlevels);
+        for (sf_long s = 0; s < nsuper; ++s) by_level[level[s]].push_back(s);
+        for (int l = 0; l < nlevels; ++l) {
+            sf_long maxcol = 0;
+            for (sf_long s : by_level[l]) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
+            for (int diag = 0; diag < maxcol; diag += sf::NB) {
+                sf_chol_plan::SolveStep st{};
+                st.diag_first = (int64_t)solve.size();
+                for (sf_long s : by_level[l]) {
+                    const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                    if (diag >= nscol) continue;
+                    solve.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, std::min(sf::NB, nscol - diag), 0, 0, (int32_t)Super[s]});
+                }
+                st.diag_count = (int)(solve.size() - st.diag_first);
+                for (int dir = 0; dir < 2; ++dir) {         // 0: forward tiles of 256 rows, 1: backward tiles of 1024 rows
+                    const int tile = dir ? 1024 : 256;
+                    const int64_t first = (int64_t)solve.size();
+                    for (sf_long s : by_level[l]) {
+                        const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                        if (diag >= nscol) continue;
+                        const int b = std::min(sf::NB, nscol - diag);
+                        for (int r = diag + b; r < nsrow; r += tile)
+                            solve.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, b, r, std::min(tile, nsrow - r), (int32_t)Super[s]});
+                    }
+                    if (dir) { st.bwd_first = first; st.bwd_count = (int)(solve.size() - first); }
+                    else { st.fwd_first = first; st.fwd_count = (int)(solve.size() - first); }
+                }
+                p->solve_steps.push_back(st);
+            }
+        }
+    }
+
     // K-step prefix of every GEMM launch (stream-K work distribution, see k_gemm)
     std::vector<uint32_t> ktprefix;
     for (Launch& L : p->launches) {
@@ -475,6 +516,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
         if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
+        if (!solve.empty()) {
+            if ((rc = upload(&p->d_solve, solve, &p->bytes_device))) break;
+            if (hipMalloc((void**)&p->d_x, std::max<int64_t>(n, 1) * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += std::max<int64_t>(n, 1) * sizeof(double);
+        }
         if (lu || p->partial) {
             if ((rc = upload(&p->d_Xp, XP, &p->bytes_device))) break;
         }
@@ -697,6 +743,7 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     if (!p || !name) return -1;
     const std::string k(name);
     if (k == "levels") return p->nlevels;
+    if (k == "last_solve_ms") return p->last_solve_ms;
     if (k == "top_doubles") return (double)p->top_size;
     if (k == "stored_doubles") return (double)p->xC;
     if (k == "launches") return (double)p->launches.size();
@@ -719,9 +766,34 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     return -1;
 }
 
+// x <- (L L^T)^{-1} b with the resident factor, permuted space (device twin of SparseFrame_solve_supernodal, C:3036-3139)
 int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host) {
-    (void)p; (void)b_host; (void)x_host;
-    return SF_ERR_ARG;   // device solve: not built yet; host solve is SparseFrame_solve_supernodal
+    if (!p || !b_host || !x_host) return SF_ERR_ARG;
+    if (p->lu || p->partial || (p->nsuper > 0 && !p->d_solve)) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = p->stream;
+    if (p->n <= 0) return SF_OK;
+    HIP_TRY(hipMemcpyAsync(p->d_x, b_host, p->n * sizeof(double), hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (const auto& s : p->solve_steps) {
+        sf::launch_solve_fwd_diag(p->d_solve + s.diag_first, s.diag_count, p->d_Lsx, p->d_x, st);
+        sf::launch_solve_fwd_update(p->d_solve + s.fwd_first, s.fwd_count, p->d_Lsx, p->d_Lsi, p->d_x, st);
+    }
+    for (size_t k = p->solve_steps.size(); k-- > 0;) {
+        const auto& s = p->solve_steps[k];
+        sf::launch_solve_bwd_update(p->d_solve + s.bwd_first, s.bwd_count, p->d_Lsx, p->d_Lsi, p->d_x, st);
+        sf::launch_solve_bwd_diag(p->d_solve + s.diag_first, s.diag_count, p->d_Lsx, p->d_x, st);
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(x_host, p->d_x, p->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) p->last_solve_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return SF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

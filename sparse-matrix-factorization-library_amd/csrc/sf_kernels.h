@@ -68,13 +68,18 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st)
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
                  int mode, double* Lsx, const int32_t* Lsi, hipStream_t st, int ablate = 0);
 
-// device-side supernodal triangular solves (one launch per level of the supernodal tree)
+// ---- device-side supernodal triangular solves with the resident factor (reference: scalar host loops,
+// Cholesky/Source/SparseFrame.c:3074-3134).  64-column block steps, the same (level, step) sweep as the factorization.
 struct SolveTask {
-    int64_t panel;      // doubles
-    int64_t rows;       // index into Lsi
-    int32_t nscol, nsrow;
+    int64_t panel;      // doubles, into Lsx
+    int64_t rows;       // index into Lsi of the supernode's row list
+    int32_t ld, diag, b;
+    int32_t row0, nrows;    // update kernels: rows [row0, row0 + nrows) of the panel (below the block)
+    int32_t first_col;      // Super[s]
 };
-void launch_solve_fwd(const SolveTask* tasks, int ntasks, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
-void launch_solve_bwd(const SolveTask* tasks, int ntasks, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
+void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st);
+void launch_solve_fwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
+void launch_solve_bwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
+void launch_solve_bwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st);
 
 }  // namespace sf

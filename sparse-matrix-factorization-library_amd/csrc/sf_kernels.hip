@@ -252,6 +252,104 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Triangular solves with the resident Cholesky factor (L L^T x = b, permuted space), 64-column block steps.
+//   forward : x_blk <- D^{-1} x_blk (one wave, row r of D in lane r's registers) ; x[rows below] -= L[rows, blk] x_blk
+//   backward: x_blk -= L[rows below, blk]^T x[rows below]                        ; x_blk <- D^{-T} x_blk
+// Several supernodes of one level update the same ancestor entries of x: fp64 atomics.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_solve_fwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, double* __restrict__ x) {
+    const SolveTask t = tasks[blockIdx.x];
+    const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
+    const int lane = threadIdx.x, b = t.b;
+    const int64_t ld = t.ld;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = (lane < b && c <= lane) ? D[lane + c * ld] : ((c == lane) ? 1.0 : 0.0);
+    double* xb = x + t.first_col + t.diag;
+    double v = (lane < b) ? xb[lane] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double xj = readlane_f64(v, j) / readlane_f64(a[j], j);
+        if (lane == j) v = xj;
+        if (lane > j) v -= a[j] * xj;
+    }
+    if (lane < b) xb[lane] = v;
+}
+
+__global__ void __launch_bounds__(256)
+k_solve_fwd_update(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
+                   double* __restrict__ x) {
+    __shared__ double xb[NB];
+    const SolveTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < NB) xb[tid] = (tid < t.b) ? x[t.first_col + t.diag + tid] : 0.0;
+    __syncthreads();
+    if (tid >= t.nrows) return;
+    const int r = t.row0 + tid;
+    const double* Lr = Lsx + t.panel + r + (int64_t)t.diag * t.ld;
+    double acc = 0.0;
+    for (int k = 0; k < t.b; ++k) acc += Lr[(int64_t)k * t.ld] * xb[k];
+    unsafeAtomicAdd(x + Lsi[t.rows + r], -acc);
+}
+
+// one workgroup per tile of up to 1024 rows; wave w sums columns w, w+4, ... of the block over the tile's rows
+__global__ void __launch_bounds__(256)
+k_solve_bwd_update(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
+                   double* __restrict__ x) {
+    __shared__ double xr[1024];
+    const SolveTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < t.nrows; i += 256) xr[i] = x[Lsi[t.rows + t.row0 + i]];
+    __syncthreads();
+    const double* Lt = Lsx + t.panel + t.row0 + (int64_t)t.diag * t.ld;
+    for (int c = wave; c < t.b; c += 4) {
+        const double* col = Lt + (int64_t)c * t.ld;
+        double acc = 0.0;
+        for (int i = lane; i < t.nrows; i += 64) acc += col[i] * xr[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) unsafeAtomicAdd(x + t.first_col + t.diag + c, -acc);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_solve_bwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, double* __restrict__ x) {
+    __shared__ double Dl[NB][NB + 1];
+    const SolveTask t = tasks[blockIdx.x];
+    const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
+    const int lane = threadIdx.x, b = t.b;
+    for (int c = 0; c < b; ++c)
+        if (lane < b) Dl[c][lane] = (lane >= c) ? D[lane + (int64_t)c * t.ld] : 0.0;     // Dl[c][r] = D(r,c), coalesced along r
+    __syncthreads();
+    double bcol[NB];    // bcol[c] = D(c, lane): column `lane` of D, rows c >= lane
+#pragma unroll
+    for (int c = 0; c < NB; ++c) bcol[c] = (lane < b && c < b && c >= lane) ? Dl[lane][c] : ((c == lane) ? 1.0 : 0.0);
+    double* xb = x + t.first_col + t.diag;
+    double v = (lane < b) ? xb[lane] : 0.0;
+#pragma unroll
+    for (int j = NB - 1; j >= 0; --j) {
+        const double xj = readlane_f64(v, j) / readlane_f64(bcol[j], j);
+        if (lane == j) v = xj;
+        if (lane < j) v -= bcol[j] * xj;           // D(j, lane) * x_j
+    }
+    if (lane < b) xb[lane] = v;
+}
+
+void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd_diag, dim3(nt), dim3(64), 0, st, t, Lsx, x);
+}
+void launch_solve_fwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd_update, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x);
+}
+void launch_solve_bwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_bwd_update, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x);
+}
+void launch_solve_bwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_bwd_diag, dim3(nt), dim3(64), 0, st, t, Lsx, x);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // fp64 MFMA GEMM  C[ci][cj] -= sum_k Y[ci][k] X[cj][k]   (lower trapezoid ci >= cj)
 //
 // Workgroup = 4 waves (2 x 2), tile 128 (ci) x 128 (cj), K step 16, double-buffered LDS.
