@@ -42,6 +42,7 @@ struct Launch {
     int count;
     int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
     uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
+    double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
 };
 
 #define HIP_TRY(expr)                                                                       \
@@ -475,9 +476,16 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (L.kind < 2) continue;
         L.prefix_first = (int64_t)ktprefix.size();
         uint64_t run = 0;
+        int32_t last_prob = -1;
         for (int k = 0; k < L.count; ++k) {
             ktprefix.push_back((uint32_t)run);
-            run += (uint64_t)((probs[gtasks[L.first + k].prob].K + sf::GEMM_BK - 1) / sf::GEMM_BK);
+            const int32_t pi = gtasks[L.first + k].prob;
+            const GemmProb& g = probs[pi];
+            run += (uint64_t)((g.K + sf::GEMM_BK - 1) / sf::GEMM_BK);
+            if (pi != last_prob) {      // tasks of one problem are contiguous
+                L.flops += (double)g.N * (g.N + 1) * g.K + 2.0 * (double)(g.M - g.N) * g.N * g.K;
+                last_prob = pi;
+            }
         }
         if (run >= (uint64_t)0x7fffffff) { delete p; return SF_ERR_ARG; }   // one launch holds < 2^31 units
         ktprefix.push_back((uint32_t)run);
@@ -538,7 +546,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 p->bytes_device += ub;
             }
         }
-        const size_t xb = std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
+        // + 2 doubles: the GEMM stages row PAIRS with 16-byte loads and may touch 8 bytes past the last panel
+        const size_t xb = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
             hipMalloc((void**)&p->d_info, sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
         p->bytes_device += xb + vb + sizeof(int);
@@ -662,11 +671,19 @@ int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
         }
         float ms = 0;
         if (first && !evs.empty() && hipEventElapsedTime(&ms, p->ev0, evs[0]) == hipSuccess) p->last_load_ms = ms;
+        FILE* dump = nullptr;
+        if (const char* path = getenv("SF_PROFILE_DUMP")) dump = fopen(path, first ? "w" : "a");
+        if (dump && first) fprintf(dump, "launch,kind,tasks,units,flops,ms\n");
         for (size_t k = 0; k + 1 < evs.size(); ++k) {
             if (hipEventElapsedTime(&ms, evs[k], evs[k + 1]) != hipSuccess) continue;
             if (kinds[k] == 3) p->last_update_ms += ms; else p->last_panel_ms += ms;
             p->last_kind_ms[kinds[k]] += ms;
+            if (dump) {
+                const Launch& L = p->launches[l0 + k];
+                fprintf(dump, "%zu,%d,%d,%u,%.6e,%.4f\n", l0 + k, L.kind, L.count, L.units, L.flops, ms);
+            }
         }
+        if (dump) fclose(dump);
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
     if (sync) {

@@ -18,6 +18,7 @@
 namespace sf {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte vector that may sit on an 8-byte boundary
 
 // position of `key` in the ascending array a[0..n); key is known to be present
 __device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, int n, int32_t key) {
@@ -384,8 +385,8 @@ __global__ void __launch_bounds__(256, 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks,
        double* __restrict__ Lsx, const int32_t* __restrict__ Lsi, int ablate) {
-    __shared__ double Ys[2][GEMM_BK][LDS_LD];
-    __shared__ double Xs[2][GEMM_BK][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Ys[2][GEMM_BK][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Xs[2][GEMM_BK][LDS_LD];
     __shared__ int32_t rowmap[GEMM_BM];
     __shared__ int32_t colmap[GEMM_BN];
 
@@ -393,7 +394,6 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 15, fk = lane >> 4;
-    const int lrow = tid & 127, lk0 = tid >> 7;
 
     // XCD-aware share: workgroups b, b+8, b+16 ... run on one XCD (one L2); give each XCD a contiguous
     // run of shares so that the tiles it works on at any time are neighbours (supertile order).
@@ -444,46 +444,42 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
             }
         }
 
-        // global -> register staging: lane handles row (tid & 127), k = (tid >> 7) + 2*q, q = 0..7.
-        // Loads are unconditional (row clamped to a valid one, zeroed when staged into LDS); only the
-        // last, partial K step of a problem takes the masked path.
-        const bool yrow_ok = (ci0 + lrow) < M, xrow_ok = (cj0 + lrow) < N;
-        const double* __restrict__ yp = Yg + (yrow_ok ? lrow : 0) + (int64_t)lk0 * lda;
-        const double* __restrict__ xp = Xg + (xrow_ok ? lrow : 0) + (int64_t)lk0 * lda;
-        const int64_t qstride = 2 * (int64_t)lda;
-        double ry[8], rx[8];
+        // global -> register staging: lane handles the ROW PAIR (2*(tid & 63), +1) for k = (tid >> 6) + 4*q, q = 0..3:
+        // one 16-byte load and one ds_write_b128 per pair (a wave reads 128 consecutive rows = 1 KiB of one panel
+        // column).  gfx950 services 16-byte global loads from 8-byte-aligned addresses (tools/unaligned_load_test.hip),
+        // so no alignment of the panel offsets is required.  Loads are unconditional: rows are clamped to a valid
+        // pair and k to K-1; the values of invalid rows / k are zeroed when they are staged into LDS.
+        const int prow = 2 * (tid & 63), pk0 = tid >> 6;
+        const bool y0_ok = (ci0 + prow) < M, y1_ok = (ci0 + prow + 1) < M;
+        const bool x0_ok = (cj0 + prow) < N, x1_ok = (cj0 + prow + 1) < N;
+        const double* __restrict__ yp = Yg + (y0_ok ? prow : 0);
+        const double* __restrict__ xp = Xg + (x0_ok ? prow : 0);
+        double2_t ry[4], rx[4];
 
         auto load_tile = [&](int k0) {
-            const double* __restrict__ y = yp + (int64_t)k0 * lda;
-            const double* __restrict__ x = xp + (int64_t)k0 * lda;
-            if (k0 + GEMM_BK <= K) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    ry[q] = y[q * qstride];
-                    rx[q] = x[q * qstride];
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const bool kin = (k0 + lk0 + 2 * q) < K;
-                    const int64_t off = kin ? q * qstride : 0;
-                    const double vy = y[off], vx = x[off];
-                    ry[q] = kin ? vy : 0.0;
-                    rx[q] = kin ? vx : 0.0;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int64_t off = (int64_t)min(k0 + pk0 + 4 * q, K - 1) * lda;
+                ry[q] = *reinterpret_cast<const double2_t*>(yp + off);
+                rx[q] = *reinterpret_cast<const double2_t*>(xp + off);
             }
         };
-        auto store_tile = [&](int buf) {
+        auto store_tile = [&](int buf, int k0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                Ys[buf][lk0 + 2 * q][lrow] = yrow_ok ? ry[q] : 0.0;
-                Xs[buf][lk0 + 2 * q][lrow] = xrow_ok ? rx[q] : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const bool kin = (k0 + pk0 + 4 * q) < K;
+                double2_t vy = ry[q], vx = rx[q];
+                vy.x = (kin && y0_ok) ? vy.x : 0.0; vy.y = (kin && y1_ok) ? vy.y : 0.0;
+                vx.x = (kin && x0_ok) ? vx.x : 0.0; vx.y = (kin && x1_ok) ? vx.y : 0.0;
+                *reinterpret_cast<double2_t*>(&Ys[buf][pk0 + 4 * q][prow]) = vy;
+                *reinterpret_cast<double2_t*>(&Xs[buf][pk0 + 4 * q][prow]) = vx;
             }
         };
 
         // a wave whose 64x64 quadrant lies entirely outside the lower trapezoid does no MFMA work
+        // (wave-uniform by construction; readfirstlane lets the compiler branch on it with the scalar unit)
         const int qci0 = ci0 + wm * 64, qcj0 = cj0 + wn * 64;
-        const bool quad_active = (qci0 < M) && (qcj0 < N) && (qci0 + 63 >= qcj0);
+        const bool quad_active = __builtin_amdgcn_readfirstlane((int)((qci0 < M) && (qcj0 < N) && (qci0 + 63 >= qcj0))) != 0;
 
         double4_t acc[4][4];
 #pragma unroll
@@ -491,15 +487,16 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
+        // Software pipeline, one barrier per K step: while step kt is multiplied out of LDS buffer `buf`, the
+        // registers holding step kt+1 are written to the other buffer and re-filled with step kt+2 -- both in
+        // the shadow of this wave's own MFMAs (an MFMA occupies the matrix pipe for 64 cycles after it issues).
         load_tile(kt0 * GEMM_BK);
+        store_tile(0, kt0 * GEMM_BK);
+        __syncthreads();
+        load_tile((kt0 + 1) * GEMM_BK);
         int buf = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            // `ablate` is 0 in the product; tools/gemm_bench sets bits to time the loop without one of its
-            // parts (1: no global loads after the first step, 2: no LDS staging stores, 4: no barrier)
-            if (!(ablate & 2) || kt == kt0) store_tile(buf);
-            if (!(ablate & 4) || kt == kt0) __syncthreads();
-            if (kt + 1 < kt1 && (!(ablate & 1))) load_tile((kt + 1) * GEMM_BK);
-            if (quad_active) {
+        if (quad_active) {
+            for (int kt = kt0; kt < kt1; ++kt) {
 #pragma unroll
                 for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
                     double a[4], b[4];
@@ -508,14 +505,24 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                         a[t] = Xs[buf][kk * 4 + fk][wn * 64 + t * 16 + fr];
                         b[t] = Ys[buf][kk * 4 + fk][wm * 64 + t * 16 + fr];
                     }
+                    if (kk == 0) store_tile(buf ^ 1, (kt + 1) * GEMM_BK);
+                    if (kk == 1) load_tile((kt + 2) * GEMM_BK);
 #pragma unroll
                     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < 4; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
                 }
+                __syncthreads();
+                buf ^= 1;
             }
-            buf ^= 1;
+        } else {
+            for (int kt = kt0; kt < kt1; ++kt) {     // staging only, same barriers
+                store_tile(buf ^ 1, (kt + 1) * GEMM_BK);
+                load_tile((kt + 2) * GEMM_BK);
+                __syncthreads();
+                buf ^= 1;
+            }
         }
 
         if (quad_active) {

@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
     const int64_t ld = M;
     const size_t elems = (size_t)ld * (K + N);
     double* d;
-    CK(hipMalloc(&d, elems * sizeof(double)));
+    CK(hipMalloc(&d, (elems + 2) * sizeof(double)));
     std::vector<double> h((size_t)ld * 64);
     for (size_t i = 0; i < h.size(); ++i) h[i] = ((double)rand() / RAND_MAX - 0.5) * 1e-3;
     for (size_t off = 0; off < elems; off += h.size())
