@@ -11,6 +11,8 @@ constexpr int TRSM_ROWS = 256;  // rows per TRSM workgroup (one row per lane)
 constexpr int GEMM_BM = 128;    // tile extent along ci (target rows; contiguous in memory)
 constexpr int GEMM_BN = 128;    // tile extent along cj (target columns)
 constexpr int GEMM_BK = 16;
+constexpr int GEMM_WAVES = 8;     // waves per GEMM workgroup (2 along ci x GEMM_WAVES/2 along cj)
+constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
 constexpr int GEMM_GRID = 512;   // persistent GEMM grid: 2 workgroups per CU x 256 CUs
 
 // One C -= Y * X^T problem on rows of ONE source panel (column-major, leading dimension lda):

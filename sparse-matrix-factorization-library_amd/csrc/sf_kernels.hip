@@ -381,7 +381,7 @@ __device__ __forceinline__ int last_le_u32(const uint32_t* __restrict__ a, int n
 // whatever the mix of tile counts and K lengths in the launch (no tail of half-empty rounds).  A tile
 // whose K range is split between workgroups is combined with fp64 atomics in the epilogue.
 template <int MODE>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks,
        double* __restrict__ Lsx, const int32_t* __restrict__ Lsi, int ablate) {
@@ -390,9 +390,12 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
     __shared__ int32_t rowmap[GEMM_BM];
     __shared__ int32_t colmap[GEMM_BN];
 
+    constexpr int WCJ = GEMM_BN / (GEMM_WAVES / 2);     // columns (cj) per wave: 64 with 4 waves, 32 with 8
+    constexpr int TMN = WCJ / 16;                         // MFMA tiles per wave along cj
+    constexpr int SQ = GEMM_BK / GEMM_WAVES;              // staging passes per K step
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 1, wn = wave >> 1;            // wave (wm, wn) owns rows [64 wm, +64) x columns [WCJ wn, +WCJ)
     const int fr = lane & 15, fk = lane >> 4;
 
     // XCD-aware share: workgroups b, b+8, b+16 ... run on one XCD (one L2); give each XCD a contiguous
@@ -438,13 +441,13 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                                  : pb.tgt_nscol + lower_bound_i32(Lsi + pb.tgt_rows, pb.tgt_nbelow, g);
                 }
                 rowmap[tid] = v;
-            } else {
+            } else if (tid < GEMM_BM + GEMM_BN) {
                 const int cj = cj0 + (tid - GEMM_BM);
                 colmap[tid - GEMM_BM] = (cj < N) ? (Lsi[pb.src_rows + cj] - pb.tgt_first_col) : 0;
             }
         }
 
-        // global -> register staging: lane handles the ROW PAIR (2*(tid & 63), +1) for k = (tid >> 6) + 4*q, q = 0..3:
+        // global -> register staging: lane handles the ROW PAIR (2*(tid & 63), +1) for k = (tid >> 6) + GEMM_WAVES*q:
         // one 16-byte load and one ds_write_b128 per pair (a wave reads 128 consecutive rows = 1 KiB of one panel
         // column).  gfx950 services 16-byte global loads from 8-byte-aligned addresses (tools/unaligned_load_test.hip),
         // so no alignment of the panel offsets is required.  Loads are unconditional: rows are clamped to a valid
@@ -454,36 +457,36 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         const bool x0_ok = (cj0 + prow) < N, x1_ok = (cj0 + prow + 1) < N;
         const double* __restrict__ yp = Yg + (y0_ok ? prow : 0);
         const double* __restrict__ xp = Xg + (x0_ok ? prow : 0);
-        double2_t ry[4], rx[4];
+        double2_t ry[SQ], rx[SQ];
 
         auto load_tile = [&](int k0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t off = (int64_t)min(k0 + pk0 + 4 * q, K - 1) * lda;
+            for (int q = 0; q < SQ; ++q) {
+                const int64_t off = (int64_t)min(k0 + pk0 + GEMM_WAVES * q, K - 1) * lda;
                 ry[q] = *reinterpret_cast<const double2_t*>(yp + off);
                 rx[q] = *reinterpret_cast<const double2_t*>(xp + off);
             }
         };
         auto store_tile = [&](int buf, int k0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool kin = (k0 + pk0 + 4 * q) < K;
+            for (int q = 0; q < SQ; ++q) {
+                const bool kin = (k0 + pk0 + GEMM_WAVES * q) < K;
                 double2_t vy = ry[q], vx = rx[q];
                 vy.x = (kin && y0_ok) ? vy.x : 0.0; vy.y = (kin && y1_ok) ? vy.y : 0.0;
                 vx.x = (kin && x0_ok) ? vx.x : 0.0; vx.y = (kin && x1_ok) ? vx.y : 0.0;
-                *reinterpret_cast<double2_t*>(&Ys[buf][pk0 + 4 * q][prow]) = vy;
-                *reinterpret_cast<double2_t*>(&Xs[buf][pk0 + 4 * q][prow]) = vx;
+                *reinterpret_cast<double2_t*>(&Ys[buf][pk0 + GEMM_WAVES * q][prow]) = vy;
+                *reinterpret_cast<double2_t*>(&Xs[buf][pk0 + GEMM_WAVES * q][prow]) = vx;
             }
         };
 
         // a wave whose 64x64 quadrant lies entirely outside the lower trapezoid does no MFMA work
         // (wave-uniform by construction; readfirstlane lets the compiler branch on it with the scalar unit)
-        const int qci0 = ci0 + wm * 64, qcj0 = cj0 + wn * 64;
+        const int qci0 = ci0 + wm * 64, qcj0 = cj0 + wn * WCJ;
         const bool quad_active = __builtin_amdgcn_readfirstlane((int)((qci0 < M) && (qcj0 < N) && (qci0 + 63 >= qcj0))) != 0;
 
-        double4_t acc[4][4];
+        double4_t acc[TMN][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < TMN; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
@@ -499,16 +502,15 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
             for (int kt = kt0; kt < kt1; ++kt) {
 #pragma unroll
                 for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
-                    double a[4], b[4];
+                    double a[TMN], b[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        a[t] = Xs[buf][kk * 4 + fk][wn * 64 + t * 16 + fr];
-                        b[t] = Ys[buf][kk * 4 + fk][wm * 64 + t * 16 + fr];
-                    }
+                    for (int t = 0; t < TMN; ++t) a[t] = Xs[buf][kk * 4 + fk][wn * WCJ + t * 16 + fr];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[t] = Ys[buf][kk * 4 + fk][wm * 64 + t * 16 + fr];
                     if (kk == 0) store_tile(buf ^ 1, (kt + 1) * GEMM_BK);
                     if (kk == 1) load_tile((kt + 2) * GEMM_BK);
 #pragma unroll
-                    for (int tm = 0; tm < 4; ++tm)
+                    for (int tm = 0; tm < TMN; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < 4; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
@@ -529,14 +531,14 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
             double* __restrict__ Cg = Lsx + pb.c_off;
             const int64_t ldc = pb.ldc;
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
+            for (int tm = 0; tm < TMN; ++tm) {
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) {
                     const int lci = wm * 64 + tn * 16 + fr;
                     const int ci = ci0 + lci;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int lcj = wn * 64 + tm * 16 + fk + 4 * r;
+                        const int lcj = wn * WCJ + tm * 16 + fk + 4 * r;
                         const int cj = cj0 + lcj;
                         if (ci < M && cj < N && ci >= cj + pb.strict) {
                             const double v = acc[tm][tn][r];
@@ -561,9 +563,9 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
     if (ntasks <= 0 || total_units == 0) return;
     const uint32_t grid = total_units < (uint32_t)GEMM_GRID ? total_units : (uint32_t)GEMM_GRID;
     if (mode == 1)
-        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(256), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
+        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
     else
-        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(256), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
+        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
 }
 
 }  // namespace sf
