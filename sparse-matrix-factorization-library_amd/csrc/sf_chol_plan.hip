@@ -111,6 +111,7 @@ struct sf_chol_plan {
     GemmProb* d_probs = nullptr;
     GemmTask* d_gtasks = nullptr;
     uint32_t* d_ktprefix = nullptr;
+    int32_t* d_relmap = nullptr;
 
     std::vector<Launch> launches;
     int nlevels = 0;
@@ -161,7 +162,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x, p->d_relmap};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -282,6 +283,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     std::vector<TrsmTask> trsm;
     std::vector<GemmProb> probs;
     std::vector<GemmTask> gtasks;
+    int64_t relmap_size = 0;
+    std::vector<int64_t> scatter_probs;     // index of the first problem of every (s, a) pair
     // Tiles of one problem are emitted in "supertile" order: blocks of (up to) 8 tile columns x 8 tile rows.
     // The kernel hands each XCD a contiguous run of tasks, so the ~64 workgroups resident on one XCD at a
     // time work on one supertile and march through K together: per K step they touch 8 + 8 operand slices
@@ -410,6 +413,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 g.tgt_first_col = (int32_t)Super[a];
                 g.tgt_nscol = a_nscol;
                 g.tgt_nbelow = a_nsrow - a_nscol;
+                g.map_off = relmap_size;            // one relative map per (s, a) pair, shared by the L and U^T sides
+                relmap_size += dnm;
+                scatter_probs.push_back((int64_t)probs.size());
                 for (int side = 0; side < (lu ? 2 : 1); ++side) {
                     g.y_off = XP[s] + i + (side ? ushift : 0);
                     g.x_off = XP[s] + i + ((lu && !side) ? ushift : 0);
@@ -524,6 +530,21 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
         if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
+        {   // relative maps of all Schur updates, built on the device (createRelativeMap, CK:42-60, once per plan)
+            const size_t mb = (size_t)std::max<int64_t>(relmap_size, 1) * sizeof(int32_t);
+            if (hipMalloc((void**)&p->d_relmap, mb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += mb;
+            std::vector<GemmProb> firsts;
+            firsts.reserve(scatter_probs.size());
+            for (int64_t k : scatter_probs) firsts.push_back(probs[k]);
+            GemmProb* d_firsts = nullptr;
+            size_t dummy = 0;
+            if ((rc = upload(&d_firsts, firsts, &dummy))) break;
+            sf::launch_build_relmaps(d_firsts, (int)firsts.size(), p->d_Lsi, p->d_relmap, p->stream);
+            const hipError_t e1 = hipStreamSynchronize(p->stream), e2 = hipGetLastError();
+            (void)hipFree(d_firsts);
+            if (e1 != hipSuccess || e2 != hipSuccess) { rc = SF_ERR_HIP; break; }
+        }
         if (!solve.empty()) {
             if ((rc = upload(&p->d_solve, solve, &p->bytes_device))) break;
             if (hipMalloc((void**)&p->d_x, std::max<int64_t>(n, 1) * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
@@ -657,7 +678,7 @@ int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
             case 2:
             case 4: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 0, p->d_Lsx, p->d_Lsi, st); break;
-            case 3: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 1, p->d_Lsx, p->d_Lsi, st); break;
+            case 3: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 1, p->d_Lsx, p->d_relmap, st); break;
         }
         if (p->profiling) { kinds.push_back(L.kind); mark(); }
     }

@@ -33,6 +33,8 @@ struct GemmProb {
     int32_t tgt_nscol;
     int32_t tgt_nbelow;     // nsrow_a - nscol_a
     int32_t strict;         // 1: only ci > cj is produced (LU: the L panel does not own the diagonal)
+    int32_t pad_;
+    int64_t map_off;        // scatter mode: offset of this (source, ancestor) pair's relative map (M entries) in RelMap
 };
 
 struct GemmTask {   // one 128x128 tile
@@ -66,9 +68,14 @@ void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shi
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
                     const double* PL, const double* PU, double* out, int64_t ref_size, hipStream_t st);
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
+// One-time (plan creation): relative maps of all scatter problems [first, first+count) -- the device form of the
+// reference's createRelativeMap (cuda_kernel.cu:42-60): RelMap[map_off + ci] = position of source row ci in the
+// target supernode's row list.
+void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi, int32_t* RelMap, hipStream_t st);
+
 // kt_prefix[0..ntasks]: running count of 16-deep K steps of the launch's tiles (kt_prefix[ntasks] = total_units)
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
-                 int mode, double* Lsx, const int32_t* Lsi, hipStream_t st, int ablate = 0);
+                 int mode, double* Lsx, const int32_t* RelMap, hipStream_t st, int ablate = 0);
 
 // ---- device-side supernodal triangular solves with the resident factor (reference: scalar host loops,
 // Cholesky/Source/SparseFrame.c:3074-3134).  64-column block steps, the same (level, step) sweep as the factorization.

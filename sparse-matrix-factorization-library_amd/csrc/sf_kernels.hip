@@ -384,7 +384,7 @@ template <int MODE>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks,
-       double* __restrict__ Lsx, const int32_t* __restrict__ Lsi, int ablate) {
+       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap, int ablate) {
     __shared__ __attribute__((aligned(16))) double Ys[2][GEMM_BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Xs[2][GEMM_BK][LDS_LD];
     __shared__ int32_t rowmap[GEMM_BM];
@@ -431,19 +431,13 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         const double* __restrict__ Xg = Lsx + pb.x_off + cj0;
 
         if (MODE == 1) {
-            // relative map of this tile's rows/columns inside the target panel
+            // relative map of this tile's rows/columns inside the target panel (precomputed once per plan)
             if (tid < GEMM_BM) {
                 const int ci = ci0 + tid;
-                int32_t v = 0;
-                if (ci < M) {
-                    const int32_t g = Lsi[pb.src_rows + ci];
-                    v = (ci < N) ? (g - pb.tgt_first_col)
-                                 : pb.tgt_nscol + lower_bound_i32(Lsi + pb.tgt_rows, pb.tgt_nbelow, g);
-                }
-                rowmap[tid] = v;
+                rowmap[tid] = (ci < M) ? RelMap[pb.map_off + ci] : 0;
             } else if (tid < GEMM_BM + GEMM_BN) {
                 const int cj = cj0 + (tid - GEMM_BM);
-                colmap[tid - GEMM_BM] = (cj < N) ? (Lsi[pb.src_rows + cj] - pb.tgt_first_col) : 0;
+                colmap[tid - GEMM_BM] = (cj < N) ? RelMap[pb.map_off + cj] : 0;
             }
         }
 
@@ -540,13 +534,13 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                     for (int r = 0; r < 4; ++r) {
                         const int lcj = wn * WCJ + tm * 16 + fk + 4 * r;
                         const int cj = cj0 + lcj;
-                        if (ci < M && cj < N && ci >= cj + pb.strict) {
+                        if (ci < M && cj < N && ci >= cj + (pb.strict & 1)) {
                             const double v = acc[tm][tn][r];
                             if (MODE == 1) {
                                 unsafeAtomicAdd(Cg + rowmap[lci] + (int64_t)colmap[lcj] * ldc, -v);
                             } else {
                                 double* dst = Cg + ci + (int64_t)cj * ldc;
-                                if (partial) unsafeAtomicAdd(dst, -v); else *dst -= v;
+                                if (partial || (pb.strict & 2)) unsafeAtomicAdd(dst, -v); else *dst -= v;   // bit 1: tools/gemm_bench only
                             }
                         }
                     }
@@ -556,6 +550,21 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         // the next tile re-uses the LDS buffers and the relative maps
         __syncthreads();
     }
+}
+
+// relative map of every scatter problem: one workgroup per problem, lanes stride over its M source rows
+__global__ void __launch_bounds__(256)
+k_build_relmaps(const GemmProb* __restrict__ probs, const int32_t* __restrict__ Lsi, int32_t* __restrict__ RelMap) {
+    const GemmProb pb = probs[blockIdx.x];
+    for (int ci = threadIdx.x; ci < pb.M; ci += blockDim.x) {
+        const int32_t g = Lsi[pb.src_rows + ci];
+        RelMap[pb.map_off + ci] = (ci < pb.N) ? (g - pb.tgt_first_col)
+                                              : pb.tgt_nscol + lower_bound_i32(Lsi + pb.tgt_rows, pb.tgt_nbelow, g);
+    }
+}
+
+void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi, int32_t* RelMap, hipStream_t st) {
+    if (nprobs > 0) hipLaunchKernelGGL(k_build_relmaps, dim3(nprobs), dim3(256), 0, st, probs, Lsi, RelMap);
 }
 
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,

@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
     sf::GemmProb pb{};
     pb.y_off = 0; pb.x_off = 0; pb.c_off = (int64_t)K * ld;
     pb.lda = M; pb.ldc = M; pb.M = M; pb.N = N; pb.K = K;
+    pb.strict = ablate ? 2 : 0;   // 5th argument != 0: force the atomic epilogue (cost of the fused scatter)
     std::vector<sf::GemmTask> tasks;
     const int tmn = (M + sf::GEMM_BM - 1) / sf::GEMM_BM, tnn = (N + sf::GEMM_BN - 1) / sf::GEMM_BN;
     const int sw = std::min(tnn, 8), sh = std::max(1, 64 / sw);

@@ -8,3 +8,5 @@ hipcc -O3 --offload-arch=gfx950 -I$P/csrc -Iinclude tools/gemm_bench.hip -L$P -l
 /tmp/gemm_bench 24576 512 8192
 /tmp/gemm_bench 8192 8192 64 20
 /tmp/gemm_bench 2048 2048 1024 20
+echo "--- plain vs atomic epilogue at small K"
+for k in 128 256 512 1024; do /tmp/gemm_bench 16384 16384 $k 6 0; /tmp/gemm_bench 16384 16384 $k 6 1; done
