@@ -99,8 +99,12 @@ k_potrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int
     for (int j = 0; j < NB; ++j) {
         const double djj = readlane_f64(a[j], j);
         bad = bad || !(djj > 0.0);          // also catches NaN; padded rows have djj = 1
-        const double d = sqrt(djj);
-        const double rinv = 1.0 / d;
+        // 1/sqrt(djj) from v_rsq_f64 + two Newton steps (full fp64 accuracy for normal inputs), d = djj * rinv:
+        // the IEEE sqrt and divide sequences are ~10x longer and sit on the 64-step sequential critical path
+        double rinv = __builtin_amdgcn_rsq(djj);
+        rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
+        rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
+        const double d = djj * rinv;
         const double lj = (lane == j) ? d : ((lane > j) ? a[j] * rinv : 0.0);
         a[j] = lj;
 #pragma unroll
