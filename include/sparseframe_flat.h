@@ -85,6 +85,11 @@ double sf_symbolic_flops(const sf_symbolic *sym, int which);
  * leaf^3 nodes in natural order.  perm[new] = old.  Stands in for METIS (unpinned third party). */
 int sf_grid_nd_perm(sf_long nx, sf_long ny, sf_long nz, sf_long leaf, sf_long sep_width, sf_long *perm);
 
+/* Built-in fill-reducing ordering for a general symmetric pattern (any triangle or both in Cp/Ci): nested dissection
+ * by BFS level-structure separators, pieces of at most `leaf` vertices in reverse BFS order.  perm[new] = old.
+ * A self-contained stand-in for the reference's METIS_NodeND call (C:942); orderings are outside the parity contract. */
+int sf_graph_nd_perm(sf_long n, const sf_long *Cp, const sf_long *Ci, sf_long leaf, sf_long *perm);
+
 /* ---- device plan for supernodal Cholesky (replaces C:2150-3017 + CK:22-158) ---- */
 typedef struct sf_chol_plan sf_chol_plan;
 

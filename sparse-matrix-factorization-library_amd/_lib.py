@@ -63,6 +63,8 @@ lib.sf_device_memory.argtypes = [C.c_int]
 lib.sf_device_memory.restype = C.c_size_t
 lib.sf_reference_slot_size.argtypes = [C.c_int, C.c_size_t]
 lib.sf_reference_slot_size.restype = C.c_size_t
+lib.sf_graph_nd_perm.argtypes = [C.c_int64, c_long_p, c_long_p, C.c_int64, c_long_p]
+lib.sf_graph_nd_perm.restype = C.c_int
 lib.sf_grid_nd_perm.argtypes = [C.c_int64] * 5 + [c_long_p]
 lib.sf_grid_nd_perm.restype = C.c_int
 

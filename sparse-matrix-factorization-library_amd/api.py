@@ -48,6 +48,14 @@ def grid_nd_perm(nx, ny=1, nz=1, leaf=3, sep_width=1):
     return perm
 
 
+def graph_nd_perm(n, Cp, Ci, leaf=64):
+    """Built-in nested dissection (BFS level-structure separators) for a general symmetric pattern; perm[new] = old."""
+    Cp, Ci = _i64(Cp), _i64(Ci)
+    perm = np.empty(max(n, 1), dtype=np.int64)
+    check(lib.sf_graph_nd_perm(n, _lp(Cp), _lp(Ci), leaf, _lp(perm)), "sf_graph_nd_perm")
+    return perm[:n]
+
+
 class Symbolic:
     """Result of the host-side symbolic analysis (flat ABI)."""
 
@@ -428,6 +436,10 @@ class MatrixInfo:
     def set_perm(self, perm):
         perm = _i64(perm)
         check(self._lib.SparseFrame_set_perm(C.byref(self.c), _lp(perm)), "SparseFrame_set_perm")
+
+    def use_builtin_ordering(self):
+        """permMethod = PERM_METIS with no Perm supplied: SparseFrame_analyze orders with the built-in nested dissection"""
+        self.c.permMethod = 2
 
     def analyze(self, common):
         check(self._lib.SparseFrame_analyze(C.byref(common.c), C.byref(self.c)), "SparseFrame_analyze")

@@ -175,6 +175,10 @@ int sf_subtree_partition(sf_long nsuper, const sf_long* Super, const sf_long* Su
     return sf::subtree_partition(nsuper, Super, SuperMap, Lsip, Lsi, nranks, owner, top_fraction, max_load_fraction) ? SF_ERR_ARG : SF_OK;
 }
 
+int sf_graph_nd_perm(sf_long n, const sf_long* Cp, const sf_long* Ci, sf_long leaf, sf_long* perm) {
+    return sf::graph_nd_perm(n, Cp, Ci, leaf, perm) ? SF_ERR_ARG : SF_OK;
+}
+
 int sf_grid_nd_perm(sf_long nx, sf_long ny, sf_long nz, sf_long leaf, sf_long sep_width, sf_long* perm) {
     return sf::grid_nd_perm(nx, ny, nz, leaf, sep_width, perm) ? SF_ERR_ARG : SF_OK;
 }
@@ -295,6 +299,13 @@ int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_st
     const double t0 = wall_seconds();
     sf::Symbolic S;
     const sf_long* perm = (mi->permMethod != PERM_IDENTITY) ? mi->Perm : nullptr;
+    std::vector<Long> builtin;
+    if (mi->permMethod != PERM_IDENTITY && !mi->Perm) {
+        // the reference orders with METIS_NodeND here (C:1937); the built-in stand-in is BFS nested dissection
+        builtin.resize(mi->nrow);
+        if (sf::graph_nd_perm(mi->nrow, mi->Cp, mi->Ci, 64, builtin.data())) return 1;
+        perm = builtin.data();
+    }
     int rc = sf::analyze_cholesky(mi->nrow, mi->Cp, mi->Ci, mi->Cx, perm, common->devSlotSize, S);
     if (rc) return rc;
 

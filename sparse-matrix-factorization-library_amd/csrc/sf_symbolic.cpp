@@ -645,6 +645,138 @@ int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Built-in fill-reducing ordering for general patterns: nested dissection by BFS level structures.
+// (The reference calls METIS_NodeND, Cholesky/Source/SparseFrame.c:942, a third-party library; this is NOT a
+// restatement of METIS -- it is a self-contained stand-in so that SparseFrame_analyze is usable without a caller-
+// supplied ordering.  Orderings are not part of the parity contract: every downstream array is defined for a GIVEN Perm.)
+//
+// For a connected piece: BFS from a pseudo-peripheral vertex (two sweeps), the vertex separator is the BFS level
+// that best balances the two sides; the two sides are ordered first (recursively), the separator last.  Pieces
+// of at most `leaf` vertices are ordered by BFS (reverse Cuthill-McKee like), which keeps their fill banded.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct NdCtx {
+    const std::vector<Long>& Ap;
+    const std::vector<Long>& Ai;
+    std::vector<Long> mark;      // mark[v] = id of the piece v currently belongs to
+    std::vector<Long> level;
+    Long* out;
+    Long pos = 0;
+    Long leaf;
+};
+
+// BFS inside piece `id` from `root`; returns the vertices in BFS order and fills level[]
+void nd_bfs(NdCtx& c, Long id, Long root, std::vector<Long>& order) {
+    order.clear();
+    order.push_back(root);
+    c.level[root] = 0;
+    // visited flag: reuse level with a generation trick -> use a local set via negative ids is overkill; mark with -2-id
+    c.mark[root] = -2 - id;
+    for (size_t h = 0; h < order.size(); ++h) {
+        const Long v = order[h];
+        for (Long p = c.Ap[v]; p < c.Ap[v + 1]; ++p) {
+            const Long w = c.Ai[p];
+            if (c.mark[w] == id) {
+                c.mark[w] = -2 - id;
+                c.level[w] = c.level[v] + 1;
+                order.push_back(w);
+            }
+        }
+    }
+    for (Long v : order) c.mark[v] = id;    // restore
+}
+
+void nd_component(NdCtx& c, std::vector<Long>& comp, Long& next_id);
+
+// `verts`: vertices carrying one common mark.  Its connected components are peeled off one after the other
+// (iteratively: a diagonal matrix has n components) and dissected.
+void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long& next_id) {
+    const Long id = c.mark[verts[0]];
+    std::vector<Long> comp;
+    for (Long v : verts) {
+        if (c.mark[v] != id) continue;          // already ordered as part of an earlier component
+        nd_bfs(c, id, v, comp);
+        const Long cid = next_id++;
+        for (Long w : comp) c.mark[w] = cid;
+        nd_component(c, comp, next_id);
+    }
+}
+
+// one connected piece, all vertices marked with one id; `comp` is in BFS order from some vertex of it
+void nd_component(NdCtx& c, std::vector<Long>& comp, Long& next_id) {
+    std::vector<Long>& verts = comp;
+    const Long id = c.mark[verts[0]];
+    if ((Long)verts.size() <= c.leaf) {
+        // BFS order from a pseudo-peripheral vertex, reversed
+        std::vector<Long> o2;
+        nd_bfs(c, id, comp.back(), o2);
+        for (size_t k = o2.size(); k-- > 0;) { c.out[c.pos++] = o2[k]; c.mark[o2[k]] = -1; }
+        return;
+    }
+    // pseudo-peripheral root: restart the BFS from the last vertex of the previous one
+    std::vector<Long> order;
+    nd_bfs(c, id, comp.back(), order);
+    const Long nlev = c.level[order.back()] + 1;
+    if (nlev < 3) {     // (nearly) complete graph: no useful separator
+        for (size_t k = order.size(); k-- > 0;) { c.out[c.pos++] = order[k]; c.mark[order[k]] = -1; }
+        return;
+    }
+    std::vector<Long> cnt(nlev, 0);
+    for (Long v : order) cnt[c.level[v]]++;
+    // separator level: minimise max(|below|, |above|) + |level| over interior levels
+    Long best = 1, best_cost = -1, below = cnt[0];
+    const Long total = (Long)order.size();
+    for (Long l = 1; l + 1 < nlev; ++l) {
+        const Long above = total - below - cnt[l];
+        const Long cost = std::max(below, above) + cnt[l];
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = l; }
+        below += cnt[l];
+    }
+    std::vector<Long> A, B, Sep;
+    const Long ida = next_id++, idb = next_id++;
+    for (Long v : order) {
+        if (c.level[v] < best) { A.push_back(v); c.mark[v] = ida; }
+        else if (c.level[v] > best) { B.push_back(v); c.mark[v] = idb; }
+        else Sep.push_back(v);
+    }
+    for (Long v : Sep) c.mark[v] = -1;       // removed from the graph for the recursion
+    if (!A.empty()) nd_recurse(c, A, next_id);
+    if (!B.empty()) nd_recurse(c, B, next_id);
+    for (Long v : Sep) c.out[c.pos++] = v;
+}
+}  // namespace
+
+// Cp/Ci: any triangle (or both) of the symmetric pattern; the pattern is symmetrised.  perm[new] = old.
+int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm) {
+    if (n < 0 || !Cp || (n > 0 && !Ci) || !perm || leaf < 1) return 1;
+    std::vector<Long> Ap(n + 1, 0), Ai;
+    for (Long j = 0; j < n; ++j)
+        for (Long p = Cp[j]; p < Cp[j + 1]; ++p) {
+            const Long i = Ci[p];
+            if (i < 0 || i >= n) return 1;
+            if (i != j) { Ap[i + 1]++; Ap[j + 1]++; }
+        }
+    for (Long j = 0; j < n; ++j) Ap[j + 1] += Ap[j];
+    Ai.resize(Ap[n]);
+    {
+        std::vector<Long> fill(Ap.begin(), Ap.end() - 1);
+        for (Long j = 0; j < n; ++j)
+            for (Long p = Cp[j]; p < Cp[j + 1]; ++p) {
+                const Long i = Ci[p];
+                if (i != j) { Ai[fill[i]++] = j; Ai[fill[j]++] = i; }
+            }
+    }
+    NdCtx c{Ap, Ai, std::vector<Long>(n, 0), std::vector<Long>(n, 0), perm, 0, leaf};
+    if (n == 0) return 0;
+    std::vector<Long> all(n);
+    for (Long v = 0; v < n; ++v) all[v] = v;
+    Long next_id = 1;
+    nd_recurse(c, all, next_id);    // recursion depth = dissection depth, O(log n) for balanced level separators
+    if (c.pos != n) return 2;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // geometric nested dissection on a regular grid
 // ---------------------------------------------------------------------------------------------
 namespace {

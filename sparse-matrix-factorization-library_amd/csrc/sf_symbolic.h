@@ -58,6 +58,8 @@ double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems
 int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi,
                       int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction);
 
+int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm);
+
 int grid_nd_perm(Long nx, Long ny, Long nz, Long leaf, Long sepw, Long* perm);
 
 }  // namespace sf
