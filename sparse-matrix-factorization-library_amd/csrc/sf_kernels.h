@@ -75,7 +75,7 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
 
 // kt_prefix[0..ntasks]: running count of 16-deep K steps of the launch's tiles (kt_prefix[ntasks] = total_units)
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
-                 int mode, double* Lsx, const int32_t* RelMap, hipStream_t st, int ablate = 0);
+                 int mode, double* Lsx, const int32_t* RelMap, hipStream_t st);
 
 // ---- device-side supernodal triangular solves with the resident factor (reference: scalar host loops,
 // Cholesky/Source/SparseFrame.c:3074-3134).  64-column block steps, the same (level, step) sweep as the factorization.

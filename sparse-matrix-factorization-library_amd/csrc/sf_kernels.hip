@@ -1,16 +1,20 @@
-// Hand-written gfx950 (CDNA4) kernels of the supernodal Cholesky numeric phase.
+// Hand-written gfx950 (CDNA4) kernels of the supernodal Cholesky / no-pivot LU numeric phase.
+// Reference citations: C: = Cholesky/Source/SparseFrame.c, L: = LU/Source/SparseFrame.c, CK: = Cholesky/Source/cuda_kernel.cu.
 //
-//   k_load_panels  : reference SparseFrame_loadA  (Cholesky/Source/SparseFrame.c:1998-2028) for ALL supernodes
-//                    in one launch; the inverse row map (createMap, cuda_kernel.cu:22-30) is replaced by a
-//                    binary search in the supernode's sorted row list.
-//   k_potrf_block  : dpotrf_('L') on one <=64x64 diagonal block held in LDS       (C:2135, C:2766)
-//   k_trsm_block   : dtrsm_('R','L','C','N') of a row tile against that block     (C:2142, C:2773)
-//   k_gemm<mode>   : fp64 MFMA (v_mfma_f64_16x16x4_f64) C -= Y X^T on LDS-staged panels
-//       mode 0 : in-panel trailing update (the reference's blocked potrf SYRK/GEMM, C:2854-2863)
-//       mode 1 : Schur-complement update of an ancestor panel: dsyrk+dgemm (C:2061-2070) with the
-//                relative map (createRelativeMap, cuda_kernel.cu:42-50) built in the prologue and the
-//                mapped scatter-subtract (mappedSubtract, cuda_kernel.cu:62-124; CPU loop C:2073-2086)
-//                fused into the epilogue as native global_atomic_add_f64, lower trapezoid only.
+//   k_load_panels   : SparseFrame_loadA (C:1998-2028, L:2478-2536) for ALL supernodes in one launch; the inverse row map
+//                     (createMap, CK:22-30) is replaced by a binary search in the supernode's sorted row list.
+//   k_potrf_block   : dpotrf_('L') on one <= 64x64 diagonal block, one wavefront, registers only   (C:2135, C:2766)
+//   k_getrf_block   : no-pivot LU of the block (magma_dgetrf_nopiv L:2653, cusolverDnDgetrf/NULL L:3344), same scheme
+//   k_trsm_block    : dtrsm_('R','L','C','N') of a row tile against that block (C:2142, C:2773); LU: D from the
+//                     other panel, optional unit diagonal (L:2660)
+//   k_gemm<mode>    : fp64 MFMA (v_mfma_f64_16x16x4_f64) C -= Y X^T on LDS-staged panels, persistent stream-K grid
+//       mode 0 : in-panel updates (the reference's blocked-potrf SYRK/GEMM, C:2854-2863)
+//       mode 1 : Schur-complement update of an ancestor panel: dsyrk+dgemm (C:2061-2070; LU: L:2570-2577) with the
+//                mapped scatter-subtract (mappedSubtract, CK:62-124; CPU loops C:2073-2086, L:2583-2604) fused into
+//                the epilogue as native global_atomic_add_f64, lower trapezoid only
+//   k_build_relmaps : createRelativeMap (CK:42-60), once per plan for every (descendant, ancestor) pair
+//   k_pack_lu       : gathers the device's (L, U^T) panel pairs into the reference's packed LU panels (L:2514-2517)
+//   k_solve_*       : level-scheduled triangular solves with the resident factor (host loops C:3074-3134)
 //
 // Wavefronts are 64 wide; all tilings below are written for that.
 #include "sf_kernels.h"
@@ -388,7 +392,7 @@ template <int MODE>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks,
-       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap, int ablate) {
+       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap) {
     __shared__ __attribute__((aligned(16))) double Ys[2][GEMM_BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Xs[2][GEMM_BK][LDS_LD];
     __shared__ int32_t rowmap[GEMM_BM];
@@ -544,7 +548,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                                 unsafeAtomicAdd(Cg + rowmap[lci] + (int64_t)colmap[lcj] * ldc, -v);
                             } else {
                                 double* dst = Cg + ci + (int64_t)cj * ldc;
-                                if (partial || (pb.strict & 2)) unsafeAtomicAdd(dst, -v); else *dst -= v;   // bit 1: tools/gemm_bench only
+                                if (partial || (pb.strict & 2)) unsafeAtomicAdd(dst, -v); else *dst -= v;   // strict bit 1: forced by tools/gemm_bench only
                             }
                         }
                     }
@@ -572,13 +576,13 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
 }
 
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
-                 int mode, double* Lsx, const int32_t* Lsi, hipStream_t st, int ablate) {
+                 int mode, double* Lsx, const int32_t* RelMap, hipStream_t st) {
     if (ntasks <= 0 || total_units == 0) return;
     const uint32_t grid = total_units < (uint32_t)GEMM_GRID ? total_units : (uint32_t)GEMM_GRID;
     if (mode == 1)
-        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
+        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, RelMap);
     else
-        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, Lsi, ablate);
+        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, RelMap);
 }
 
 }  // namespace sf

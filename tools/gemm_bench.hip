@@ -15,7 +15,7 @@
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 16384, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 8192;
     const int reps = argc > 4 ? atoi(argv[4]) : 5;
-    const int ablate = argc > 5 ? atoi(argv[5]) : 0;
+    const int force_atomic = argc > 5 ? atoi(argv[5]) : 0;
     const int64_t ld = M;
     const size_t elems = (size_t)ld * (K + N);
     double* d;
@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     sf::GemmProb pb{};
     pb.y_off = 0; pb.x_off = 0; pb.c_off = (int64_t)K * ld;
     pb.lda = M; pb.ldc = M; pb.M = M; pb.N = N; pb.K = K;
-    pb.strict = ablate ? 2 : 0;   // 5th argument != 0: force the atomic epilogue (cost of the fused scatter)
+    pb.strict = force_atomic ? 2 : 0;   // 5th argument != 0: force the atomic epilogue (cost of the fused scatter)
     std::vector<sf::GemmTask> tasks;
     const int tmn = (M + sf::GEMM_BM - 1) / sf::GEMM_BM, tnn = (N + sf::GEMM_BN - 1) / sf::GEMM_BN;
     const int sw = std::min(tnn, 8), sh = std::max(1, 64 / sw);
@@ -54,13 +54,13 @@ int main(int argc, char** argv) {
     float best = 1e30f;
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0));
-        sf::launch_gemm(dp, dt, dpre, (int)tasks.size(), pre.back(), 0, d, nullptr, 0, ablate);
+        sf::launch_gemm(dp, dt, dpre, (int)tasks.size(), pre.back(), 0, d, nullptr, 0);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (r > 0 || reps == 1) best = std::min(best, ms);
     }
-    printf("gemm<0> ablate=%d M=%d N=%d K=%d tiles=%zu  %.3f ms  algorithmic %.2f TFLOP/s  (tile-executed %.2f TFLOP/s)\n", ablate, M, N, K,
+    printf("gemm<0> atomic=%d M=%d N=%d K=%d tiles=%zu  %.3f ms  algorithmic %.2f TFLOP/s  (tile-executed %.2f TFLOP/s)\n", force_atomic, M, N, K,
            tasks.size(), best, alg / best / 1e9, exec / best / 1e9);
     return 0;
 }
