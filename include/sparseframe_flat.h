@@ -157,6 +157,8 @@ int sf_lu_plan_sync(sf_lu_plan *plan);
 /* D2H copy of the factor gathered into the reference layout: panel s = (2*nsrow-nscol) x nscol column-major,
  * rows [0,nscol) packed L11\U11, [nscol,nsrow) L21, [nsrow,2*nsrow-nscol) U12^T (L:2514-2517) */
 int sf_lu_plan_get_factor(sf_lu_plan *plan, sf_float *Lsx);
+/* device-side solve with the resident factors: x <- (L U)^{-1} b, permuted space (device twin of L:3592-3700) */
+int sf_lu_plan_solve(sf_lu_plan *plan, const sf_float *b_host, sf_float *x_host);
 double sf_lu_plan_stat(const sf_lu_plan *plan, const char *name);
 int sf_lu_plan_set_profiling(sf_lu_plan *plan, int on);
 int sf_lu_plan_destroy(sf_lu_plan *plan);

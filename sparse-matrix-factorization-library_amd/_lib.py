@@ -108,6 +108,8 @@ lib.sf_lu_plan_sync.argtypes = [C.c_void_p]
 lib.sf_lu_plan_sync.restype = C.c_int
 lib.sf_lu_plan_get_factor.argtypes = [C.c_void_p, c_double_p]
 lib.sf_lu_plan_get_factor.restype = C.c_int
+lib.sf_lu_plan_solve.argtypes = [C.c_void_p, c_double_p, c_double_p]
+lib.sf_lu_plan_solve.restype = C.c_int
 lib.sf_lu_plan_stat.argtypes = [C.c_void_p, C.c_char_p]
 lib.sf_lu_plan_stat.restype = C.c_double
 lib.sf_lu_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]

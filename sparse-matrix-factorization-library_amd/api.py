@@ -277,6 +277,12 @@ class LUPlan:
         check(lib.sf_lu_plan_get_factor(self._h, _dp(out)), "sf_lu_plan_get_factor")
         return out[:self.xsize]
 
+    def solve(self, b):
+        b = _f64(b)
+        x = np.empty_like(b)
+        check(lib.sf_lu_plan_solve(self._h, _dp(b), _dp(x)), "sf_lu_plan_solve")
+        return x
+
     def stat(self, name):
         return float(lib.sf_lu_plan_stat(self._h, name.encode()))
 

@@ -441,9 +441,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     }   // phases
     p->n_gemm_tasks = (int64_t)gtasks.size();
 
-    // ---------------- device solve schedule (Cholesky, unsharded) ----------------
+    // ---------------- device solve schedule (unsharded plans) ----------------
     std::vector<sf::SolveTask> solve;
-    if (!lu && !p->partial) {
+    if (!p->partial) {
         std::vector<std::vector<sf_long>> by_level(nlevels);
         for (sf_long s = 0; s < nsuper; ++s) by_level[level[s]].push_back(s);
         for (int l = 0; l < nlevels; ++l) {
@@ -767,6 +767,7 @@ int sf_lu_plan_sync(sf_lu_plan* p) { return sf_chol_plan_sync(p); }
 int sf_lu_plan_get_factor(sf_lu_plan* p, sf_float* Lsx) { return (p && p->lu) ? sf_chol_plan_get_factor(p, Lsx) : SF_ERR_ARG; }
 double sf_lu_plan_stat(const sf_lu_plan* p, const char* name) { return sf_chol_plan_stat(p, name); }
 int sf_lu_plan_set_profiling(sf_lu_plan* p, int on) { return sf_chol_plan_set_profiling(p, on); }
+int sf_lu_plan_solve(sf_lu_plan* p, const sf_float* b_host, sf_float* x_host) { return (p && p->lu) ? sf_chol_plan_solve(p, b_host, x_host) : SF_ERR_ARG; }
 int sf_lu_plan_destroy(sf_lu_plan* p) { return sf_chol_plan_destroy(p); }
 
 void* sf_chol_plan_factor_device_ptr(sf_chol_plan* p) { return p ? (void*)p->d_Lsx : nullptr; }
@@ -804,10 +805,13 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     return -1;
 }
 
-// x <- (L L^T)^{-1} b with the resident factor, permuted space (device twin of SparseFrame_solve_supernodal, C:3036-3139)
+// x <- (L L^T)^{-1} b (Cholesky, C:3036-3139) or (L U)^{-1} b (LU, L:3592-3700) with the resident factor, permuted
+// space.  LU: unit-lower forward sweep over the L panels, backward sweep over the U^T panels (U x = y <=> (U^T)^T x = y).
 int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host) {
     if (!p || !b_host || !x_host) return SF_ERR_ARG;
-    if (p->lu || p->partial || (p->nsuper > 0 && !p->d_solve)) return SF_ERR_ARG;
+    if (p->partial || (p->nsuper > 0 && !p->d_solve)) return SF_ERR_ARG;
+    const double* fwd_base = p->d_Lsx;
+    const double* bwd_base = p->lu ? p->d_Lsx + p->xC : p->d_Lsx;
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
     if (p->n <= 0) return SF_OK;
@@ -816,13 +820,13 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, st));
     for (const auto& s : p->solve_steps) {
-        sf::launch_solve_fwd_diag(p->d_solve + s.diag_first, s.diag_count, p->d_Lsx, p->d_x, st);
-        sf::launch_solve_fwd_update(p->d_solve + s.fwd_first, s.fwd_count, p->d_Lsx, p->d_Lsi, p->d_x, st);
+        sf::launch_solve_fwd_diag(p->d_solve + s.diag_first, s.diag_count, fwd_base, p->d_x, st, p->lu ? 1 : 0);
+        sf::launch_solve_fwd_update(p->d_solve + s.fwd_first, s.fwd_count, fwd_base, p->d_Lsi, p->d_x, st);
     }
     for (size_t k = p->solve_steps.size(); k-- > 0;) {
         const auto& s = p->solve_steps[k];
-        sf::launch_solve_bwd_update(p->d_solve + s.bwd_first, s.bwd_count, p->d_Lsx, p->d_Lsi, p->d_x, st);
-        sf::launch_solve_bwd_diag(p->d_solve + s.diag_first, s.diag_count, p->d_Lsx, p->d_x, st);
+        sf::launch_solve_bwd_update(p->d_solve + s.bwd_first, s.bwd_count, bwd_base, p->d_Lsi, p->d_x, st);
+        sf::launch_solve_bwd_diag(p->d_solve + s.diag_first, s.diag_count, bwd_base, p->d_x, st);
     }
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipGetLastError());

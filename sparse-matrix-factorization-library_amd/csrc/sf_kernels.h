@@ -86,7 +86,7 @@ struct SolveTask {
     int32_t row0, nrows;    // update kernels: rows [row0, row0 + nrows) of the panel (below the block)
     int32_t first_col;      // Super[s]
 };
-void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st);
+void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st, int unit = 0);
 void launch_solve_fwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
 void launch_solve_bwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
 void launch_solve_bwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st);

@@ -267,14 +267,14 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st)
 // Several supernodes of one level update the same ancestor entries of x: fp64 atomics.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_solve_fwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, double* __restrict__ x) {
+k_solve_fwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, double* __restrict__ x, int unit) {
     const SolveTask t = tasks[blockIdx.x];
     const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
     const int lane = threadIdx.x, b = t.b;
     const int64_t ld = t.ld;
-    double a[NB];
+    double a[NB];       // unit: the diagonal is implied (LU: the L panel stores only the strictly lower part)
 #pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = (lane < b && c <= lane) ? D[lane + c * ld] : ((c == lane) ? 1.0 : 0.0);
+    for (int c = 0; c < NB; ++c) a[c] = (lane < b && c + unit <= lane) ? D[lane + c * ld] : ((c == lane) ? 1.0 : 0.0);
     double* xb = x + t.first_col + t.diag;
     double v = (lane < b) ? xb[lane] : 0.0;
 #pragma unroll
@@ -345,8 +345,8 @@ k_solve_bwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__
     if (lane < b) xb[lane] = v;
 }
 
-void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd_diag, dim3(nt), dim3(64), 0, st, t, Lsx, x);
+void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st, int unit) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd_diag, dim3(nt), dim3(64), 0, st, t, Lsx, x, unit);
 }
 void launch_solve_fwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st) {
     if (nt > 0) hipLaunchKernelGGL(k_solve_fwd_update, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x);

@@ -98,6 +98,11 @@ def test_lu_gpu_matches_oracle(oracle, case):
     assert rel_err(Lsx, ref) <= TOL_FACTOR
     res, _ = oracle.lu_residual(S, Lsx)
     assert res <= TOL_RESIDUAL
+    # device-side solve (unit-lower forward, U backward) against the reference's host loops (oracle restatement)
+    b = 1 + np.arange(n) / n
+    x = plan.solve(b)
+    want = oracle.lu_solve(S, Lsx, b)
+    assert np.allclose(x, want, rtol=1e-12, atol=1e-13 * np.abs(want).max())
     plan.close()
 
 
