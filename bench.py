@@ -8,10 +8,12 @@ geometric nested dissection, devSlotSize = the reference's formula for one 288 G
 A "step" = one complete numeric factorization (assemble + every panel + every Schur update) with the
 matrix values, the symbolic structure and the task tables already resident in HBM; the factor stays
 in HBM.  value = F_struct * N / t  with  F_struct = sum_j ColCount_j^2  (SURVEY 8d).
-N > 1 (default --mp subtree): ONE factorization of the same matrix sharded over the N GPUs by elimination-tree
-subtrees: own subtrees -> one RCCL sum all-reduce of the top-panel region -> replicated top
-supernodes; "strong" scaling (the Amdahl bound of subtree-only sharding is printed in config.sharding).
---mp replicas: one independent matrix per GPU (the reference's multi-matrix mode, SparseFrame.c:3375), "weak".
+N > 1 (default --mp subtree): ONE factorization sharded over the N GPUs by elimination-tree subtrees:
+own subtrees on their GPU, then the top supernodes with their large GEMMs split over the ranks and every top panel
+summed once over RCCL, block by block (sharded.py, mode "distributed").  --scale weak (default): the grid grows
+with N so that the flops per GPU stay those of 128^3 (g = round(128 N^(1/6)): 144, 161, 181 -- towards BASELINE
+config 4); --scale strong: the same 128^3 matrix on every N.  --mp subtree-replicated: top supernodes replicated,
+one all-reduce.  --mp replicas: one independent matrix per GPU (the reference's multi-matrix mode, SparseFrame.c:3375).
 
 The JSON line also carries
   roofline     : the Schur-update kernel (k_gemm<1>: fp64 MFMA GEMM + fused mapped scatter), executed
@@ -44,8 +46,11 @@ def main():
     ap.add_argument("--workload", choices=["lap3d", "stencil2d"], default="lap3d",
                     help="cholesky only: lap3d = N^3 7-point Laplacian (config 2); stencil2d = N x N grid, 21-point random SPD "
                          "stencil, 2-line separators (BASELINE config 3 at N = 1000)")
-    ap.add_argument("--mp", choices=["subtree", "replicas"], default="subtree",
-                    help="N > 1: shard one matrix by elimination-tree subtrees (default) or run one matrix per GPU")
+    ap.add_argument("--mp", choices=["subtree", "subtree-replicated", "replicas"], default="subtree",
+                    help="N > 1: shard one matrix by elimination-tree subtrees (default: distributed top; "
+                         "subtree-replicated: replicated top) or run one matrix per GPU")
+    ap.add_argument("--scale", choices=["weak", "strong"], default="weak",
+                    help="N > 1 with --mp subtree*: weak = grid round(base * N^(1/6)) (flops per GPU fixed), strong = base grid")
     ap.add_argument("--check", action="store_true", help="download the factor and check the residual on the host")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -79,6 +84,9 @@ def main():
 
     lu = args.method == "lu"
     N = args.grid or (79 if lu else (1000 if args.workload == "stencil2d" else 128))
+    shard_one = world > 1 and args.mp.startswith("subtree") and not lu
+    if shard_one and args.scale == "weak" and args.workload == "lap3d":
+        N = int(round(N * world ** (1.0 / 6.0)))      # F ~ g^6: the flops per GPU stay those of the base grid
     t0 = time.time()
 
     def make(M):
@@ -97,8 +105,9 @@ def main():
 
     t0 = time.time()
     sharded = None
-    if world > 1 and args.mp == "subtree" and not lu:
-        sharded = sf.ShardedCholesky(sym, rank, world, device=local_rank)
+    if shard_one:
+        sharded = sf.ShardedCholesky(sym, rank, world, device=local_rank,
+                                     mode="distributed" if args.mp == "subtree" else "replicated")
         sharded.set_values(sym.Lx)
         plan = sharded.engine.plan
     elif lu:
@@ -141,7 +150,7 @@ def main():
     out = {
         "metric": "numeric-factorization GFLOP/s (supernodal %s)" % ("no-pivot LU" if lu else "Cholesky"),
         "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if sharded is not None else "weak",
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if (sharded is not None and args.scale == "strong") else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"unsymmetric 3D 19-point stencil {N}^3 (5% of entries dropped one-sidedly), diagonally dominant, "
                                 f"no-pivot LU fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if lu else
@@ -150,8 +159,11 @@ def main():
                                f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
                    "n": n, "nnz_input": int(nnz_in), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
                    "F_struct": F_struct, "F_exec": F_exec,
-                   "parallelism": ("elimination-tree subtrees sharded over the GPUs, one RCCL all-reduce of the top panels, "
-                                   "top supernodes replicated") if sharded is not None else
+                   "parallelism": (("elimination-tree subtrees sharded over the GPUs; top supernodes: large GEMMs split over the "
+                                    "ranks, every top panel all-reduced once (RCCL) block by block, 64-column chains replicated")
+                                   if sharded.mode == "distributed" else
+                                   ("elimination-tree subtrees sharded over the GPUs, one RCCL all-reduce of the top panels, "
+                                    "top supernodes replicated")) if sharded is not None else
                                   ("1 matrix per GPU (independent)" if ngpu > 1 else "single GPU"),
                    "sharding": sharded.plan_info() if sharded is not None else None,
                    "exec_GFLOPs": round(F_exec * units / (elapsed / args.steps) / 1e9, 2),

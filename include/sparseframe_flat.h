@@ -141,6 +141,34 @@ int sf_chol_plan_factorize_phase(sf_chol_plan *plan, int phase /* 0, 1, or -1 = 
 /* device pointer and length (doubles) of the contiguous region holding every top panel */
 int sf_chol_plan_top_region(sf_chol_plan *plan, void **device_ptr, sf_long *count);
 
+/* ---- distributed top: the top supernodes' large GEMMs are SPLIT over the ranks instead of
+ * replicated.  Every top panel is summed over the ranks exactly once, one 512-column block at a time, right before
+ * the block's sequential 64-column POTRF/TRSM chain (the only replicated work); everything that updates a block
+ * before that -- subtree Schur updates, top-level Schur updates, the block's large-K left-looking GEMM -- is additive,
+ * so each rank applies only ITS share (units [rank, rank+1) * units / nranks of the stream-K launch) to its own copy.
+ *     sf_chol_plan_factorize_phase(plan, 0)                    own subtrees (as above)
+ *     for k in 0 .. sf_chol_plan_num_segments(plan) - 1:
+ *         all-reduce(sum) of every region of segment k         (RCCL over xGMI; regions are offsets into
+ *         sf_chol_plan_factorize_segment(plan, k)               sf_chol_plan_factor_device_ptr, in doubles)
+ * sf_subtree_partition_weighted: partition cost = top_weight * top flops + heaviest rank's subtree flops
+ * (top_weight 1 = replicated top; about 1/nranks + the chain's share for the distributed top).
+ * sf_chol_plan_set_stream: run the plan on a caller-owned HIP stream (e.g. the stream the collectives are ordered
+ * with), so that segments and all-reduces need no host synchronisation between them. ---- */
+int sf_subtree_partition_weighted(sf_long nsuper, const sf_long *Super, const sf_long *SuperMap, const sf_long *Lsip,
+                                  const sf_long *Lsi, int nranks, double top_weight, int32_t *owner,
+                                  double *top_fraction, double *max_load_fraction);
+int sf_chol_plan_create_distributed(sf_chol_plan **plan, int device, sf_long n, sf_long nsuper,
+                                    const sf_long *Super, const sf_long *SuperMap,
+                                    const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                                    const sf_long *Lp, const sf_long *Li, const int32_t *phase, int load_top,
+                                    int rank, int nranks);
+sf_long sf_chol_plan_num_segments(const sf_chol_plan *plan);
+/* offsets/counts may be NULL to query *nregions only */
+int sf_chol_plan_segment_regions(const sf_chol_plan *plan, sf_long k, sf_long capacity, sf_long *nregions,
+                                 sf_long *offsets, sf_long *counts);
+int sf_chol_plan_factorize_segment(sf_chol_plan *plan, sf_long k, int sync);
+int sf_chol_plan_set_stream(sf_chol_plan *plan, void *hip_stream);
+
 /* ---- device plan for supernodal no-pivot LU (replaces L:2668-3573 + LU/Source/cuda_kernel.cu:22-176).
  * Symbolic arrays from sf_symbolic_create_lu; Lsxp is the reference's (packed (2*nsrow-nscol) x nscol) offsets.
  * Up/Ui = U by row; pass NULL for both when the input is symmetric (U aliases L, L:2718-2729).

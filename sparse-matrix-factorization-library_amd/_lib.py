@@ -98,6 +98,20 @@ lib.sf_chol_plan_factorize_phase.argtypes = [C.c_void_p, C.c_int, C.c_int]
 lib.sf_chol_plan_factorize_phase.restype = C.c_int
 lib.sf_chol_plan_top_region.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), c_long_p]
 lib.sf_chol_plan_top_region.restype = C.c_int
+lib.sf_subtree_partition_weighted.argtypes = [C.c_int64, c_long_p, c_long_p, c_long_p, c_long_p, C.c_int, C.c_double,
+                                              C.POINTER(C.c_int32), c_double_p, c_double_p]
+lib.sf_subtree_partition_weighted.restype = C.c_int
+lib.sf_chol_plan_create_distributed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7 + \
+    [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int]
+lib.sf_chol_plan_create_distributed.restype = C.c_int
+lib.sf_chol_plan_num_segments.argtypes = [C.c_void_p]
+lib.sf_chol_plan_num_segments.restype = C.c_int64
+lib.sf_chol_plan_segment_regions.argtypes = [C.c_void_p, C.c_int64, C.c_int64, c_long_p, c_long_p, c_long_p]
+lib.sf_chol_plan_segment_regions.restype = C.c_int
+lib.sf_chol_plan_factorize_segment.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+lib.sf_chol_plan_factorize_segment.restype = C.c_int
+lib.sf_chol_plan_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+lib.sf_chol_plan_set_stream.restype = C.c_int
 lib.sf_lu_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9
 lib.sf_lu_plan_create.restype = C.c_int
 lib.sf_lu_plan_set_values.argtypes = [C.c_void_p, c_double_p, c_double_p]

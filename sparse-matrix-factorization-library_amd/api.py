@@ -154,14 +154,16 @@ def validate_solution(sym, x, b=None):
     return float(np.abs(r).max() / (colsum.max() * np.abs(x).max() + np.abs(b).max()))
 
 
-def subtree_partition(sym, nranks):
-    """owner[s] = rank of the elimination-tree subtree holding supernode s, -1 for the replicated top supernodes.
+def subtree_partition(sym, nranks, top_weight=1.0):
+    """owner[s] = rank of the elimination-tree subtree holding supernode s, -1 for the top supernodes.
+    top_weight: cost of a top flop relative to a subtree flop (1 = replicated top, ~1/nranks = distributed top).
     Returns (owner int32[nsuper], top flop fraction, heaviest rank's subtree flop fraction)."""
     owner = np.empty(max(sym.nsuper, 1), dtype=np.int32)
     tf, ml = C.c_double(), C.c_double()
-    check(lib.sf_subtree_partition(sym.nsuper, _lp(sym.Super), _lp(sym.SuperMap), _lp(sym.Lsip), _lp(sym.Lsi), nranks,
-                                   owner.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(tf), C.byref(ml)),
-          "sf_subtree_partition")
+    check(lib.sf_subtree_partition_weighted(sym.nsuper, _lp(sym.Super), _lp(sym.SuperMap), _lp(sym.Lsip), _lp(sym.Lsi),
+                                            nranks, float(top_weight), owner.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            C.byref(tf), C.byref(ml)),
+          "sf_subtree_partition_weighted")
     return owner[:sym.nsuper], tf.value, ml.value
 
 
@@ -172,19 +174,27 @@ def phases_for_rank(owner, rank):
 
 class CholPlan:
     """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present.
-    phase/load_top: multi-GPU sharding (sf_chol_plan_create_sharded); default = the whole matrix on one device."""
+    phase/load_top: multi-GPU sharding (sf_chol_plan_create_sharded); default = the whole matrix on one device.
+    rank/nranks (with phase): distributed top (sf_chol_plan_create_distributed), run with factorize_phase(0) and then
+    factorize_segment(k) after summing segment_regions(k) over the ranks."""
 
-    def __init__(self, sym, device=0, phase=None, load_top=True):
+    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1):
         h = C.c_void_p()
         self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
         if phase is None:
             check(lib.sf_chol_plan_create(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep]),
                   "sf_chol_plan_create")
-        else:
+        elif nranks <= 1:
             phase = np.ascontiguousarray(phase, dtype=np.int32)
             check(lib.sf_chol_plan_create_sharded(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
                                                   phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0),
                   "sf_chol_plan_create_sharded")
+        else:
+            phase = np.ascontiguousarray(phase, dtype=np.int32)
+            check(lib.sf_chol_plan_create_distributed(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
+                                                      phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0,
+                                                      int(rank), int(nranks)),
+                  "sf_chol_plan_create_distributed")
         self.device = device
         self._h = h
         self.xsize = sym.xsize
@@ -199,6 +209,26 @@ class CholPlan:
 
     def factorize_phase(self, which, sync=True):
         check(lib.sf_chol_plan_factorize_phase(self._h, which, 1 if sync else 0), "sf_chol_plan_factorize_phase")
+
+    def num_segments(self):
+        return int(lib.sf_chol_plan_num_segments(self._h))
+
+    def segment_regions(self, k):
+        """[(offset, count)] in doubles relative to factor_device_ptr: regions to sum over the ranks before segment k"""
+        nr = C.c_int64()
+        check(lib.sf_chol_plan_segment_regions(self._h, k, 0, C.byref(nr), None, None), "sf_chol_plan_segment_regions")
+        off = np.zeros(max(nr.value, 1), dtype=np.int64)
+        cnt = np.zeros(max(nr.value, 1), dtype=np.int64)
+        check(lib.sf_chol_plan_segment_regions(self._h, k, nr.value, C.byref(nr), _lp(off), _lp(cnt)),
+              "sf_chol_plan_segment_regions")
+        return [(int(off[i]), int(cnt[i])) for i in range(nr.value)]
+
+    def factorize_segment(self, k, sync=False):
+        check(lib.sf_chol_plan_factorize_segment(self._h, k, 1 if sync else 0), "sf_chol_plan_factorize_segment")
+
+    def set_stream(self, stream_handle):
+        """run on a caller-owned HIP stream (integer handle, e.g. torch.cuda.current_stream().cuda_stream)"""
+        check(lib.sf_chol_plan_set_stream(self._h, C.c_void_p(stream_handle)), "sf_chol_plan_set_stream")
 
     def top_region(self):
         """(device pointer, number of doubles) of the contiguous top-panel region"""

@@ -43,6 +43,16 @@ struct Launch {
     int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
     uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
     double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
+    bool split = false;         // distributed top: every rank executes 1/nranks of this launch's units
+};
+
+// Distributed top phase (sf_chol_plan_create_distributed): phase 1 is cut into segments.  Before a segment runs, the
+// regions it lists (the 512-column block of every top panel of the level whose 64-column chain is about to start) are
+// summed over the ranks; until then a block only ever received additive updates (subtree Schur updates, split top
+// Schur updates, split outer GEMMs), so its true value is the sum of the ranks' copies.
+struct Segment {
+    size_t l0 = 0, l1 = 0;                 // launches [l0, l1)
+    std::vector<int64_t> off, cnt;         // doubles, relative to the factor base pointer
 };
 
 #define HIP_TRY(expr)                                                                       \
@@ -82,6 +92,9 @@ struct sf_chol_plan {
     bool partial = false;       // some supernodes are absent or the top panels are not loaded here
     int64_t top_off = 0, top_size = 0;   // contiguous region of the top panels inside one panel set
     size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
+    int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
+    std::vector<Segment> segments;
+    bool own_stream = true;
     int8_t* d_loadmask = nullptr;
     // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
     sf::SolveTask* d_solve = nullptr;
@@ -167,7 +180,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return SF_OK;
 }
@@ -186,9 +199,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                        const sf_long* Super, const sf_long* SuperMap,
                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                        const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
-                       const int32_t* phase_in = nullptr, int load_top = 1) {
+                       const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1) {
     if (!out) return SF_ERR_ARG;
     *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (lu || !phase_in))) return SF_ERR_ARG;
     if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
     if (n >= (sf_long)0x7fffffff) return SF_ERR_ARG;   // device row indices are 32-bit
     int ndev = 0;
@@ -203,6 +217,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     if (!p) return SF_ERR_ALLOC;
     p->device = device;
     p->lu = lu;
+    p->rank = rank;
+    p->nranks = nranks;
     p->n = n;
     p->nsuper = nsuper;
     p->nnz = Lp[n];
@@ -342,7 +358,23 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         add_tiles((int32_t)probs.size() - 1, g.M, g.N);
                     }
                 }
-                if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
+                if ((int64_t)gtasks.size() > g0) {
+                    p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
+                    p->launches.back().split = (ph == 1 && nranks > 1);
+                }
+            }
+            if (ph == 1 && nranks > 1) {
+                // reduce point: block column jo of every panel of the level is complete up to the sum over the ranks
+                if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
+                Segment sg;
+                sg.l0 = p->launches.size();
+                for (sf_long s : Sl) {
+                    const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+                    if (J >= nscol) continue;
+                    sg.off.push_back(XP[s] + (int64_t)J * nsrow);
+                    sg.cnt.push_back(std::min<int64_t>(sf::OUTER_NB, nscol - J) * nsrow);
+                }
+                p->segments.push_back(std::move(sg));
             }
             // Inside the outer block the 64-column steps are LEFT-looking as well: block column t is first
             // updated by the t block columns of this outer block already factored (K = 64 t, written once),
@@ -436,9 +468,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 i = e;
             }
         }
-        if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{3, g0, (int)(gtasks.size() - g0)});
+        if ((int64_t)gtasks.size() > g0) {
+            p->launches.push_back(Launch{3, g0, (int)(gtasks.size() - g0)});
+            p->launches.back().split = (ph == 1 && nranks > 1);
+        }
     }
     }   // phases
+    if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
     p->n_gemm_tasks = (int64_t)gtasks.size();
 
     // ---------------- device solve schedule (unsharded plans) ----------------
@@ -592,6 +628,15 @@ int sf_chol_plan_create_sharded(sf_chol_plan** out, int device, sf_long n, sf_lo
     return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, phase, load_top);
 }
 
+int sf_chol_plan_create_distributed(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
+                                    const sf_long* Super, const sf_long* SuperMap,
+                                    const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                                    const sf_long* Lp, const sf_long* Li, const int32_t* phase, int load_top,
+                                    int rank, int nranks) {
+    return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, phase, load_top,
+                       rank, nranks);
+}
+
 int sf_lu_plan_create(sf_lu_plan** out, int device, sf_long n, sf_long nsuper,
                       const sf_long* Super, const sf_long* SuperMap,
                       const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
@@ -630,9 +675,8 @@ int sf_chol_plan_sync(sf_chol_plan* p) {
     return p->last_status;
 }
 
-// phase 0: assemble + owned subtrees; phase 1: top supernodes; -1: both (single-GPU path)
-int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
-    if (!p || which < -1 || which > 1) return SF_ERR_ARG;
+// launches [l0, l1); first: start of a factorization (timer, memset, assembly); last: its end (timer, status)
+static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool last, int sync) {
     if (!p->values_set) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
@@ -642,7 +686,6 @@ int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
         hipEvent_t e;
         if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); evs.push_back(e); }
     };
-    const bool first = (which != 1);
     if (first) HIP_TRY(hipEventRecord(p->ev0, st));
     if (first) {
         HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), st));
@@ -666,8 +709,6 @@ int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
     }
     mark();
     std::vector<int> kinds;
-    const size_t l0 = (which == 1) ? p->launch_split : 0;
-    const size_t l1 = (which == 0) ? p->launch_split : p->launches.size();
     for (size_t li = l0; li < l1; ++li) {
         const Launch& L = p->launches[li];
         switch (L.kind) {
@@ -677,12 +718,21 @@ int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
                 break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
             case 2:
-            case 4: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 0, p->d_Lsx, p->d_Lsi, st); break;
-            case 3: sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, L.units, 1, p->d_Lsx, p->d_relmap, st); break;
+            case 3:
+            case 4: {
+                uint32_t u0 = 0, u1 = L.units;
+                if (L.split) {
+                    u0 = (uint32_t)((uint64_t)L.units * (uint64_t)p->rank / (uint64_t)p->nranks);
+                    u1 = (uint32_t)((uint64_t)L.units * (uint64_t)(p->rank + 1) / (uint64_t)p->nranks);
+                }
+                sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, u0, u1,
+                                L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, st);
+                break;
+            }
         }
         if (p->profiling) { kinds.push_back(L.kind); mark(); }
     }
-    if (which != 0) HIP_TRY(hipEventRecord(p->ev1, st));
+    if (last) HIP_TRY(hipEventRecord(p->ev1, st));
     HIP_TRY(hipGetLastError());
     if (p->profiling) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -708,11 +758,52 @@ int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
         for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
     if (sync) {
-        if (which == 0) { HIP_TRY(hipStreamSynchronize(st)); return SF_OK; }
+        if (!last) { HIP_TRY(hipStreamSynchronize(st)); return SF_OK; }
         return sf_chol_plan_sync(p);
     }
     return SF_OK;
 }
+
+// phase 0: assemble + owned subtrees; phase 1: top supernodes (replicated); -1: both (single-GPU path)
+int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
+    if (!p || which < -1 || which > 1) return SF_ERR_ARG;
+    if (p->nranks > 1 && which != 0) return SF_ERR_ARG;      // distributed top: phase 1 runs segment by segment
+    const size_t l0 = (which == 1) ? p->launch_split : 0;
+    const size_t l1 = (which == 0) ? p->launch_split : p->launches.size();
+    // a distributed plan without top supernodes (a forest of independent trees) is finished after phase 0
+    const bool last = (which != 0) || (p->nranks > 1 && p->segments.empty());
+    return run_launches(p, l0, l1, which != 1, last, sync);
+}
+
+sf_long sf_chol_plan_num_segments(const sf_chol_plan* p) { return p ? (sf_long)p->segments.size() : 0; }
+
+int sf_chol_plan_segment_regions(const sf_chol_plan* p, sf_long k, sf_long capacity, sf_long* nregions, sf_long* offsets, sf_long* counts) {
+    if (!p || k < 0 || k >= (sf_long)p->segments.size() || !nregions) return SF_ERR_ARG;
+    const Segment& sg = p->segments[k];
+    *nregions = (sf_long)sg.off.size();
+    if (offsets && counts) {
+        if (capacity < (sf_long)sg.off.size()) return SF_ERR_ARG;
+        for (size_t i = 0; i < sg.off.size(); ++i) { offsets[i] = sg.off[i]; counts[i] = sg.cnt[i]; }
+    }
+    return SF_OK;
+}
+
+int sf_chol_plan_factorize_segment(sf_chol_plan* p, sf_long k, int sync) {
+    if (!p || k < 0 || k >= (sf_long)p->segments.size()) return SF_ERR_ARG;
+    const Segment& sg = p->segments[k];
+    return run_launches(p, sg.l0, sg.l1, false, k + 1 == (sf_long)p->segments.size(), sync);
+}
+
+int sf_chol_plan_set_stream(sf_chol_plan* p, void* stream) {
+    if (!p) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->stream && p->own_stream) HIP_TRY(hipStreamDestroy(p->stream));
+    p->stream = (hipStream_t)stream;
+    p->own_stream = false;
+    return SF_OK;
+}
+
 
 int sf_chol_plan_factorize(sf_chol_plan* p, int sync) { return sf_chol_plan_factorize_phase(p, -1, sync); }
 

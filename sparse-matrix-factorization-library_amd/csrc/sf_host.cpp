@@ -175,6 +175,13 @@ int sf_subtree_partition(sf_long nsuper, const sf_long* Super, const sf_long* Su
     return sf::subtree_partition(nsuper, Super, SuperMap, Lsip, Lsi, nranks, owner, top_fraction, max_load_fraction) ? SF_ERR_ARG : SF_OK;
 }
 
+int sf_subtree_partition_weighted(sf_long nsuper, const sf_long* Super, const sf_long* SuperMap, const sf_long* Lsip,
+                                  const sf_long* Lsi, int nranks, double top_weight, int32_t* owner, double* top_fraction,
+                                  double* max_load_fraction) {
+    if (!Super || !Lsip || (nsuper > 0 && (!SuperMap || !Lsi))) return SF_ERR_ARG;
+    return sf::subtree_partition(nsuper, Super, SuperMap, Lsip, Lsi, nranks, owner, top_fraction, max_load_fraction, top_weight) ? SF_ERR_ARG : SF_OK;
+}
+
 int sf_graph_nd_perm(sf_long n, const sf_long* Cp, const sf_long* Ci, sf_long leaf, sf_long* perm) {
     return sf::graph_nd_perm(n, Cp, Ci, leaf, perm) ? SF_ERR_ARG : SF_OK;
 }

@@ -73,8 +73,9 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st)
 // target supernode's row list.
 void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi, int32_t* RelMap, hipStream_t st);
 
-// kt_prefix[0..ntasks]: running count of 16-deep K steps of the launch's tiles (kt_prefix[ntasks] = total_units)
-void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
+// kt_prefix[0..ntasks]: running count of 16-deep K steps of the launch's tiles (kt_prefix[ntasks] = total units);
+// this call executes the units [u_lo, u_hi) of the launch
+void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
                  int mode, double* Lsx, const int32_t* RelMap, hipStream_t st);
 
 // ---- device-side supernodal triangular solves with the resident factor (reference: scalar host loops,

@@ -391,7 +391,7 @@ __device__ __forceinline__ int last_le_u32(const uint32_t* __restrict__ a, int n
 template <int MODE>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
-       const uint32_t* __restrict__ kt_prefix, int ntasks,
+       const uint32_t* __restrict__ kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
        double* __restrict__ Lsx, const int32_t* __restrict__ RelMap) {
     __shared__ __attribute__((aligned(16))) double Ys[2][GEMM_BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Xs[2][GEMM_BK][LDS_LD];
@@ -408,7 +408,9 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 
     // XCD-aware share: workgroups b, b+8, b+16 ... run on one XCD (one L2); give each XCD a contiguous
     // run of shares so that the tiles it works on at any time are neighbours (supertile order).
-    const uint32_t T = kt_prefix[ntasks];
+    // [u_lo, u_hi): the units of this launch that this device executes (the whole launch on one GPU; one rank's
+    // share when the launch is split over the ranks of a sharded factorization -- the update is a sum, any split is valid)
+    const uint32_t T = u_hi - u_lo;
     const uint32_t G = gridDim.x;
     uint32_t share;
     {
@@ -416,9 +418,9 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         share = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     const uint32_t U = (T + G - 1) / G;
-    uint32_t u = share * U;
-    if (u >= T) return;
-    const uint32_t u_end = min(T, u + U);
+    if (share * U >= T) return;
+    uint32_t u = u_lo + share * U;
+    const uint32_t u_end = min(u_hi, u + U);
     int ti = last_le_u32(kt_prefix, ntasks + 1, u);
 
     while (u < u_end) {
@@ -575,14 +577,15 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
     if (nprobs > 0) hipLaunchKernelGGL(k_build_relmaps, dim3(nprobs), dim3(256), 0, st, probs, Lsi, RelMap);
 }
 
-void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t total_units,
+void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
                  int mode, double* Lsx, const int32_t* RelMap, hipStream_t st) {
-    if (ntasks <= 0 || total_units == 0) return;
-    const uint32_t grid = total_units < (uint32_t)GEMM_GRID ? total_units : (uint32_t)GEMM_GRID;
+    if (ntasks <= 0 || u_hi <= u_lo) return;
+    const uint32_t units = u_hi - u_lo;
+    const uint32_t grid = units < (uint32_t)GEMM_GRID ? units : (uint32_t)GEMM_GRID;
     if (mode == 1)
-        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, RelMap);
+        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
     else
-        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, Lsx, RelMap);
+        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
 }
 
 }  // namespace sf

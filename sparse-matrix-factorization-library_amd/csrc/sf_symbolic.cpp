@@ -562,8 +562,8 @@ double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems
 // Work of a supernode = its own factorization + every update it pushes to its ancestors (right-looking).
 // ---------------------------------------------------------------------------------------------
 int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi,
-                      int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction) {
-    if (nsuper < 0 || nranks < 1 || !owner) return 1;
+                      int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction, double top_weight) {
+    if (nsuper < 0 || nranks < 1 || !owner || !(top_weight > 0)) return 1;
     std::vector<Long> par(nsuper, -1);
     std::vector<double> fl(nsuper, 0.0), sub(nsuper, 0.0);
     std::vector<std::vector<Long>> kids(nsuper);
@@ -612,7 +612,7 @@ int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, cons
     };
     std::vector<Long> best_roots = roots;
     std::vector<char> best_top = is_top;
-    double best_t = top + estimate(roots, nullptr), best_topf = top;
+    double best_t = top_weight * top + estimate(roots, nullptr), best_topf = top;
     int stale = 0;
     while (nranks > 1 && stale < 4 * nranks) {
         // split the heaviest subtree that has children
@@ -625,7 +625,7 @@ int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, cons
         is_top[pick] = 1;
         top += fl[pick];
         for (Long c : kids[pick]) roots.push_back(c);
-        const double t = top + estimate(roots, nullptr);
+        const double t = top_weight * top + estimate(roots, nullptr);
         if (t < best_t * (1.0 - 1e-12)) { best_t = t; best_roots = roots; best_top = is_top; best_topf = top; stale = 0; }
         else ++stale;
     }

@@ -56,7 +56,7 @@ double flops_struct(const Symbolic& S);
 double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems);
 
 int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi,
-                      int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction);
+                      int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction, double top_weight = 1.0);
 
 int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm);
 

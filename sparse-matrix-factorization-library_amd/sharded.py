@@ -1,19 +1,30 @@
 """One Cholesky factorization sharded over the ranks of a torch.distributed group by elimination-tree subtrees
-(SURVEY 8e).  One process per GPU; the only data-path exchange is ONE sum all-reduce (RCCL over xGMI on GPUs,
-gloo in the CPU tests) of the contiguous top-panel region between the two phases:
+(SURVEY 8e).  One process per GPU; the data-path exchange is sum all-reduces (RCCL over xGMI on GPUs, gloo in the
+CPU tests) of top-panel regions.  Two ways of handling the top supernodes (those above the subtrees):
 
-    phase 0   every rank assembles and factorizes its own subtrees; their Schur updates into the (replicated,
-              zero-initialised except on rank 0, which also holds the matrix entries) top panels accumulate locally
-    all-reduce(sum) over the top region
-    phase 1   every rank factorizes the top supernodes (replicated; the subtree-only Amdahl limit is reported
-              by `plan_info`)
+mode "distributed" (default for world > 1)
+    phase 0       every rank assembles and factorizes its own subtrees; their Schur updates into the top panels
+                  accumulate in the rank's own copy (zero-initialised except on rank 0, which holds the matrix entries)
+    per segment   (one per top level and 512-column block) all-reduce(sum) of that block of the level's panels, then
+                  the block's sequential 64-column POTRF/TRSM chain on every rank (replicated: latency-bound), then this
+                  rank's 1/world share of the large GEMMs that follow (next block's left-looking GEMM, the level's
+                  Schur updates) -- additive, so any split is valid and nothing is exchanged until the target
+                  block's own reduce point.  Every top panel crosses xGMI exactly once.
+
+mode "replicated"
+    phase 0, ONE all-reduce over the contiguous top region, phase 1 replicated on every rank (the subtree-only
+    Amdahl limit is reported by `plan_info`).
 
 The numeric engine is pluggable: `HipEngine` (the product, libsparseframe_hip.so) or any object with the same
-three methods (tests use a numpy engine so that the orchestration runs under gloo without a GPU).
+methods (tests use a numpy engine so that the orchestration runs under gloo without a GPU).
 """
 import numpy as np
 
 from .api import CholPlan, subtree_partition, phases_for_rank
+
+#: cost of a top flop relative to a subtree flop in the distributed mode: the split share plus the replicated
+#: 64-column chain and the all-reduce (about a quarter of the top's single-GPU time at 128^3)
+TOP_CHAIN_SHARE = 0.25
 
 
 class _DevArray:
@@ -25,17 +36,28 @@ class _DevArray:
 
 
 class HipEngine:
-    def __init__(self, sym, phase, load_top, device):
-        self.plan = CholPlan(sym, device=device, phase=phase, load_top=load_top)
+    def __init__(self, sym, phase, load_top, device, rank=0, world=1, distributed=False):
+        self.distributed = bool(distributed and world > 1)
+        self.plan = CholPlan(sym, device=device, phase=phase, load_top=load_top,
+                             rank=rank if self.distributed else 0, nranks=world if self.distributed else 1)
         self.device = device
         self._top = None
+        self._seg = {}
+        if self.distributed:
+            # run on the stream the collectives are ordered with: segments and all-reduces alternate without host syncs
+            import torch
+            self.plan.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def set_values(self, Lx):
         self.plan.set_values(Lx)
 
     def factorize_phase(self, which):
-        # synchronous on the plan's own stream: the collective that follows runs on torch's stream
-        self.plan.factorize_phase(which, sync=True)
+        # replicated mode: synchronous on the plan's own stream, the collective that follows runs on torch's stream
+        self.plan.factorize_phase(which, sync=not self.distributed)
+
+    def _alias(self, offset, count):
+        import torch
+        return torch.as_tensor(_DevArray(self.plan.factor_device_ptr + 8 * offset, count), device=f"cuda:{self.device}")
 
     def top_tensor(self):
         import torch
@@ -45,6 +67,20 @@ class HipEngine:
                 torch.zeros(0, dtype=torch.float64, device=f"cuda:{self.device}")
         return self._top
 
+    def num_segments(self):
+        return self.plan.num_segments()
+
+    def segment_tensors(self, k):
+        if k not in self._seg:
+            self._seg[k] = [self._alias(o, c) for (o, c) in self.plan.segment_regions(k) if c > 0]
+        return self._seg[k]
+
+    def factorize_segment(self, k):
+        self.plan.factorize_segment(k, sync=False)
+
+    def finish(self):
+        self.plan.sync()
+
     def get_factor(self, out=None):
         return self.plan.get_factor(out)
 
@@ -53,39 +89,56 @@ class HipEngine:
 
 
 class ShardedCholesky:
-    def __init__(self, sym, rank, world, device=0, engine_factory=None, group=None):
+    def __init__(self, sym, rank, world, device=0, engine_factory=None, group=None, mode="distributed"):
+        if mode not in ("distributed", "replicated"):
+            raise ValueError("mode must be 'distributed' or 'replicated'")
         self.sym, self.rank, self.world, self.group = sym, rank, world, group
-        self.owner, self.top_fraction, self.max_load_fraction = subtree_partition(sym, world)
+        self.mode = mode if world > 1 else "replicated"
+        self.top_weight = (1.0 / world + TOP_CHAIN_SHARE) if self.mode == "distributed" else 1.0
+        self.owner, self.top_fraction, self.max_load_fraction = subtree_partition(sym, world, self.top_weight)
         phase = phases_for_rank(self.owner, rank)
-        factory = engine_factory or (lambda s, ph, lt: HipEngine(s, ph, lt, device))
-        self.engine = factory(sym, phase, rank == 0)
+        dist_mode = self.mode == "distributed"
+        factory = engine_factory or (lambda s, ph, lt, r, w, d: HipEngine(s, ph, lt, device, r, w, d))
+        self.engine = factory(sym, phase, rank == 0, rank, world, dist_mode)
         self.phase = phase
 
     def plan_info(self):
         tf, ml = self.top_fraction, self.max_load_fraction
-        return {"subtrees_per_rank": [int(np.count_nonzero(self.owner == r)) for r in range(self.world)],
+        cost = self.top_weight * tf + ml
+        return {"mode": self.mode,
+                "subtrees_per_rank": [int(np.count_nonzero(self.owner == r)) for r in range(self.world)],
                 "top_supernodes": int(np.count_nonzero(self.owner < 0)),
                 "top_flop_fraction": tf, "max_rank_subtree_flop_fraction": ml,
-                "amdahl_speedup_bound": 1.0 / (tf + ml) if tf + ml > 0 else float(self.world)}
+                "segments": self.engine.num_segments() if self.mode == "distributed" else 0,
+                "model_speedup_bound": 1.0 / cost if cost > 0 else float(self.world)}
 
     def set_values(self, Lx):
         self.engine.set_values(Lx)
 
     def factorize(self):
         import torch.distributed as dist
-        self.engine.factorize_phase(0)
+        eng = self.engine
+        eng.factorize_phase(0)
+        if self.mode == "distributed":
+            for k in range(eng.num_segments()):
+                for t in eng.segment_tensors(k):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                eng.factorize_segment(k)
+            eng.finish()
+            return
         if self.world > 1:
-            top = self.engine.top_tensor()
+            top = eng.top_tensor()
             if top.numel() > 0:
                 dist.all_reduce(top, op=dist.ReduceOp.SUM, group=self.group)
                 if top.is_cuda:
                     import torch
                     torch.cuda.synchronize(top.device)
-        self.engine.factorize_phase(1)
+        eng.factorize_phase(1)
 
     def gather_factor(self):
         """full factor in the reference layout on every rank (all-reduce of the disjoint subtree panels; the
-        replicated top panels are taken from this rank).  Test / validation helper, not part of the timed path."""
+        top panels, identical on every rank, are taken from this rank).  Test / validation helper, not part of the
+        timed path."""
         import torch
         import torch.distributed as dist
         mine = self.engine.get_factor()

@@ -19,11 +19,13 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     oracle.blas_init("builtin")
     results = []
-    for dims in ((12, 12, 1), (8, 8, 8)):
+    for dims, mode in (((12, 12, 1), "replicated"), ((8, 8, 8), "replicated"), ((12, 12, 1), "distributed"),
+                       ((8, 8, 8), "distributed")):
         n, Cp, Ci, Cx = gen.laplacian_lower(*dims)
         sym = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(*dims), 1 << 30)
-        sh = sf.ShardedCholesky(sym, rank, world, engine_factory=lambda s, ph, lt: NumpyEngine(s, ph, lt))
+        sh = sf.ShardedCholesky(sym, rank, world, engine_factory=NumpyEngine, mode=mode)
         info = sh.plan_info()
+        assert info["mode"] == mode and (info["segments"] > 0) == (mode == "distributed"), info
         assert info["top_supernodes"] > 0 and all(c > 0 for c in info["subtrees_per_rank"]), info
         # every supernode is stored by its owner, top supernodes by everybody, nothing else
         assert np.array_equal(sh.phase == 0, sh.owner == rank) and np.array_equal(sh.phase == 1, sh.owner < 0)
@@ -40,7 +42,7 @@ def main():
         sh.factorize()
         full2 = sh.gather_factor()
         assert rel_err(full2, ref * np.sqrt(2.0), oracle.lower_mask(sym)) <= 1e-12
-        results.append((dims, err, res, info["amdahl_speedup_bound"]))
+        results.append((dims, mode, err, res, info["model_speedup_bound"]))
     dist.barrier()
     if rank == 0:
         print("SHARDED_OK", results)

@@ -1,13 +1,17 @@
 """TEST-ONLY numpy engine with the interface ShardedCholesky expects from an engine (set_values, factorize_phase,
-top_tensor, get_factor).  A plain right-looking supernodal Cholesky with the same two phases and the same compact
-storage (owned panels, then the top panels, contiguous) as the HIP plan, so that the multi-rank orchestration
-(partition, the single sum all-reduce, replicated top) can be exercised under gloo without a GPU."""
+top_tensor, num_segments / segment_tensors / factorize_segment, get_factor).  A plain right-looking supernodal
+Cholesky with the same phases and the same compact storage (owned panels, then the top panels, contiguous) as the HIP
+plan, so that the multi-rank orchestration (partition, sum all-reduces, replicated or distributed top) can be exercised
+under gloo without a GPU.  Distributed top: one segment per top supernode (reduce its panel, factor it on every
+rank, then apply only the columns k = rank (mod world) of its Schur updates -- a split of the additive update)."""
 import numpy as np
 
 
 class NumpyEngine:
-    def __init__(self, sym, phase, load_top):
+    def __init__(self, sym, phase, load_top, rank=0, world=1, distributed=False):
         self.S, self.phase, self.load_top = sym, np.asarray(phase), bool(load_top)
+        self.rank, self.world, self.distributed = rank, world, bool(distributed and world > 1)
+        self.top_list = [int(s) for s in np.flatnonzero(self.phase == 1)]
         S = sym
         self.ncol = np.diff(S.Super)
         self.nrow = np.diff(S.Lsip)
@@ -43,13 +47,31 @@ class NumpyEngine:
                     for p in range(S.Lp[j], S.Lp[j + 1]):
                         A[pos[int(S.Li[p])], j - S.Super[s]] = self.Lx[p]
 
+    def num_segments(self):
+        return len(self.top_list) if self.distributed else 0
+
+    def segment_tensors(self, k):
+        import torch
+        s = self.top_list[k]
+        o = self.off[s]
+        return [torch.from_numpy(self.buf[o:o + self.ncol[s] * self.nrow[s]])]
+
+    def factorize_segment(self, k):
+        self._factor_supernodes([self.top_list[k]], split=True)
+
+    def finish(self):
+        pass
+
     def factorize_phase(self, which):
         S = self.S
         if which == 0:
             self._assemble()
-        for s in range(S.nsuper):
-            if self.phase[s] != which:
-                continue
+        assert not (self.distributed and which == 1)
+        self._factor_supernodes([s for s in range(S.nsuper) if self.phase[s] == which], split=False)
+
+    def _factor_supernodes(self, which, split):
+        S = self.S
+        for s in which:
             n, r = int(self.ncol[s]), int(self.nrow[s])
             A = self.panel(s)
             L11 = np.linalg.cholesky(np.tril(A[:n, :n]) + np.tril(A[:n, :n], -1).T)
@@ -63,7 +85,8 @@ class NumpyEngine:
                 e = i
                 while e < r and S.SuperMap[rows[e]] == a:
                     e += 1
-                C = A[i:, :] @ A[i:e, :].T                       # (r-i) x (e-i)
+                cols = slice(self.rank, None, self.world) if split else slice(None)
+                C = A[i:, cols] @ A[i:e, cols].T                 # (r-i) x (e-i)
                 arows = S.Lsi[S.Lsip[a]:S.Lsip[a + 1]]
                 rm = np.searchsorted(arows, rows[i:])
                 T = self.panel(a)

@@ -199,6 +199,63 @@ def test_sharded_plans_emulated_ranks_on_one_gpu(oracle, world):
         e.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_distributed_top_emulated_ranks_on_one_gpu(oracle, world):
+    """distributed top (sf_chol_plan_create_distributed) with every rank's plan on the single test GPU: phase 0,
+    then per segment the regions are summed through torch tensors aliasing the plans' device memory (the RCCL
+    all-reduce between GPUs) and every rank runs the segment with ITS share of the split GEMM launches.
+    24^3: the root separator has 576 > 512 columns, so a split left-looking outer GEMM is part of the run."""
+    import torch
+    from importlib import import_module
+    sharded = import_module("sparse-matrix-factorization-library_amd.sharded")
+    N = 24
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 1 << 30)
+    owner, tf, ml = sf.subtree_partition(sym, world, 1.0 / world + sharded.TOP_CHAIN_SHARE)
+    ntop = int((owner < 0).sum())
+    assert ntop > 0
+    engines = [sharded.HipEngine(sym, sf.phases_for_rank(owner, r), r == 0, 0, r, world, True) for r in range(world)]
+    nseg = engines[0].num_segments()
+    assert nseg >= 2 and all(e.num_segments() == nseg for e in engines)
+    ref, info, _ = oracle.chol_factorize(sym)
+    for rep in range(2):                                   # plans are reusable
+        for e in engines:
+            e.set_values(sym.Lx)
+            e.factorize_phase(0)
+        for k in range(nseg):
+            parts = [e.segment_tensors(k) for e in engines]
+            assert all(len(p) == len(parts[0]) for p in parts)
+            for i in range(len(parts[0])):
+                total = parts[0][i].clone()
+                for p in parts[1:]:
+                    assert p[i].numel() == total.numel()
+                    total += p[i]
+                for p in parts:
+                    p[i].copy_(total)
+            for e in engines:
+                e.factorize_segment(k)
+        for e in engines:
+            e.finish()
+        full = np.zeros(sym.xsize)
+        for e in engines:
+            e.get_factor(full)
+        assert rel_err(full, ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+        res, _ = oracle.chol_residual(sym, full)
+        assert res <= TOL_RESIDUAL
+        # the replicated chains leave the same top panels on every rank (to rounding: stream-K partial tiles use atomics)
+        t0 = engines[0].get_factor()
+        for e in engines[1:]:
+            te = e.get_factor()
+            for s_ in np.flatnonzero(owner < 0):
+                a, b = sym.Lsxp[s_], sym.Lsxp[s_ + 1]
+                assert np.abs(t0[a:b] - te[a:b]).max() <= 1e-13 * np.abs(t0[a:b]).max()
+    # a distributed plan refuses the replicated phase-1 entry point
+    with pytest.raises(RuntimeError):
+        engines[0].plan.factorize_phase(1)
+    for e in engines:
+        e.close()
+
+
 @pytest.mark.parametrize("case", small_cases(), ids=lambda c: c[0])
 def test_device_solve_matches_oracle(oracle, case):
     """sf_chol_plan_solve (level-scheduled, factor resident) vs the reference's host loops (oracle restatement)"""

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Compute-side timing of ONE rank of a W-rank distributed factorization on a single GPU (no communication).
+
+    python tools/emulate_rank.py --grid 128 --world 8 [--rank 0]
+
+Runs rank `--rank`'s phase 0 and all its top segments back to back WITHOUT the all-reduces, so the numbers in the
+factor are meaningless (the other ranks' contributions are missing) but the launches, their sizes and therefore the
+time are exactly those of that rank in a real W-GPU run.  T(W GPUs) ~ max over ranks of this time + the all-reduce
+time of `top_bytes` (printed).  Used for the scaling model in DESIGN.md section 6; the real curve comes from the
+driver's N = 1, 2, 4, 8 runs of bench.py.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=2)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    sf = importlib.import_module("sparse-matrix-factorization-library_amd")
+    sharded = importlib.import_module("sparse-matrix-factorization-library_amd.sharded")
+    g, W = args.grid, args.world
+    n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g, 3, 1), sf.REFERENCE_SLOT_1GPU)
+    owner, tf, ml = sf.subtree_partition(sym, W, 1.0 / W + sharded.TOP_CHAIN_SHARE)
+    eng = sharded.HipEngine(sym, sf.phases_for_rank(owner, args.rank), args.rank == 0, 0, args.rank, W, True)
+    eng.set_values(sym.Lx)
+    nseg = eng.num_segments()
+    top_doubles = sum(c for k in range(nseg) for (_, c) in eng.plan.segment_regions(k))
+    ncalls = sum(len(eng.plan.segment_regions(k)) for k in range(nseg))
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.factorize_phase(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(nseg):
+            eng.factorize_segment(k)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        return (t1 - t0) * 1e3, (t2 - t1) * 1e3
+
+    run()
+    res = [run() for _ in range(args.steps)]
+    p0 = min(r[0] for r in res)
+    p1 = min(r[1] for r in res)
+    print(json.dumps({"grid": g, "world": W, "rank": args.rank, "F_struct": sym.flops_struct,
+                      "phase0_ms": round(p0, 2), "segments_ms": round(p1, 2), "segments": nseg,
+                      "allreduce_calls": ncalls, "top_bytes": 8 * top_doubles,
+                      "top_flop_fraction": tf, "max_rank_subtree_flop_fraction": ml,
+                      "stored_doubles": eng.plan.stat("stored_doubles")}))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     float best = 1e30f;
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0));
-        sf::launch_gemm(dp, dt, dpre, (int)tasks.size(), pre.back(), 0, d, nullptr, 0);
+        sf::launch_gemm(dp, dt, dpre, (int)tasks.size(), 0, pre.back(), 0, d, nullptr, 0);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
