@@ -194,6 +194,7 @@ def main():
                            "load_ms": round(plan.stat("last_load_ms"), 3),
                            "potrf_ms": round(plan.stat("last_potrf_ms"), 3), "trsm_ms": round(plan.stat("last_trsm_ms"), 3),
                            "inner_gemm_ms": round(plan.stat("last_inner_gemm_ms"), 3),
+                           "fused_step_ms": round(plan.stat("last_step_ms"), 3),
                            "outer_gemm_ms": round(plan.stat("last_outer_gemm_ms"), 3),
                            "flops_outer_gemm": plan.stat("flops_outer_gemm"),
                            "flops_panel_gemm": plan.stat("flops_panel_gemm"),

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,11 +34,13 @@ using sf::GemmProb;
 using sf::GemmTask;
 using sf::PotrfTask;
 using sf::TrsmTask;
+using sf::StepTask;
 
 namespace {
 
 struct Launch {
-    int kind;       // 0 potrf, 1 trsm, 2 gemm panel (inner, K = NB), 3 gemm scatter, 4 gemm panel (outer, large K)
+    int kind;       // 0 potrf, 1 trsm, 2 gemm panel (inner, K = NB), 3 gemm scatter, 4 gemm panel (outer, large K),
+                    // 5 fused step k_step (Cholesky, steps of at most GEMM_GRID workgroups; otherwise and for LU: 2, 0, 1)
     int64_t first;  // first task
     int count;
     int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
@@ -121,6 +124,9 @@ struct sf_chol_plan {
 
     PotrfTask* d_potrf = nullptr;
     TrsmTask* d_trsm = nullptr;
+    StepTask* d_steps = nullptr;
+    int* d_flags = nullptr;     // k_step: one flag per (panel, fused step); == epoch once its diagonal block is factored
+    int epoch = 0;
     GemmProb* d_probs = nullptr;
     GemmTask* d_gtasks = nullptr;
     uint32_t* d_ktprefix = nullptr;
@@ -135,7 +141,7 @@ struct sf_chol_plan {
 
     bool profiling = false;
     double last_ms = 0, last_load_ms = 0, last_panel_ms = 0, last_update_ms = 0;
-    double last_kind_ms[5] = {0, 0, 0, 0, 0};
+    double last_kind_ms[7] = {0, 0, 0, 0, 0, 0, 0};
     int last_status = SF_OK;
 
     // host copies needed by the device solve
@@ -174,7 +180,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
-                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_probs, p->d_gtasks, p->d_ktprefix,
+                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_probs, p->d_gtasks, p->d_ktprefix,
                     p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x, p->d_relmap};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -297,6 +303,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // ---------------- task tables ----------------
     std::vector<PotrfTask> potrf;
     std::vector<TrsmTask> trsm;
+    std::vector<StepTask> steps;
     std::vector<GemmProb> probs;
     std::vector<GemmTask> gtasks;
     int64_t relmap_size = 0;
@@ -318,6 +325,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     }
     };
 
+    int32_t n_flags = 0;
     for (int ph = 0; ph < 2; ++ph) {
     if (ph == 1) p->launch_split = p->launches.size();
     std::vector<std::vector<sf_long>> by_level(nlevels);
@@ -384,6 +392,37 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             for (int ti = 0; ti < ninner; ++ti) {
                 const int diag = J + ti * sf::NB;
                 if (diag >= maxcol) break;
+                int64_t step_wgs = 0;
+                for (sf_long s : Sl) {
+                    const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+                    if (diag < nscol) step_wgs += 1 + (nsrow - std::min<int64_t>(nscol, diag + sf::NB) + sf::ST_ROWS - 1) / sf::ST_ROWS;
+                }
+                if (!lu && step_wgs <= sf::GEMM_GRID) {
+                    // Cholesky, latency-bound step (all its workgroups resident at once): the (update, POTRF, TRSM)
+                    // triple is ONE launch of k_step.  Steps with more tiles are throughput-bound and keep the three
+                    // launches (stream-K GEMM over all tiles, 256-row TRSM workgroups).
+                    const int64_t d0 = (int64_t)steps.size();
+                    std::vector<int32_t> flag_of;
+                    for (sf_long s : Sl) {
+                        const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                        if (diag >= nscol) { flag_of.push_back(-1); continue; }
+                        const int b = std::min(sf::NB, nscol - diag);
+                        flag_of.push_back(n_flags);
+                        steps.push_back(StepTask{XP[s], nsrow, J, diag, b, diag, b, n_flags++, 0});
+                        if (ti > 0) p->flops_panel_gemm += (double)b * (b + 1) * (diag - J) + 2.0 * (nsrow - diag - b) * (double)b * (diag - J);
+                    }
+                    size_t si = 0;
+                    for (sf_long s : Sl) {
+                        const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                        const int32_t fl = flag_of[si++];
+                        if (fl < 0) continue;
+                        const int b = std::min(sf::NB, nscol - diag);
+                        for (int r = diag + b; r < nsrow; r += sf::ST_ROWS)
+                            steps.push_back(StepTask{XP[s], nsrow, J, diag, b, r, std::min(sf::ST_ROWS, nsrow - r), fl, 0});
+                    }
+                    if ((int64_t)steps.size() > d0) p->launches.push_back(Launch{5, d0, (int)(steps.size() - d0)});
+                    continue;
+                }
                 const int64_t p0 = (int64_t)potrf.size(), t0 = (int64_t)trsm.size(), g0 = (int64_t)gtasks.size();
                 for (sf_long s : Sl) {
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
@@ -515,7 +554,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // K-step prefix of every GEMM launch (stream-K work distribution, see k_gemm)
     std::vector<uint32_t> ktprefix;
     for (Launch& L : p->launches) {
-        if (L.kind < 2) continue;
+        if (L.kind < 2 || L.kind > 4) continue;
         L.prefix_first = (int64_t)ktprefix.size();
         uint64_t run = 0;
         int32_t last_prob = -1;
@@ -563,6 +602,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if ((rc = upload(&p->d_Lsxp, Lsxp64, &p->bytes_device))) break;
         if ((rc = upload(&p->d_potrf, potrf, &p->bytes_device))) break;
         if ((rc = upload(&p->d_trsm, trsm, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_steps, steps, &p->bytes_device))) break;
+        {
+            std::vector<int> zeros(std::max<int32_t>(n_flags, 1), 0);
+            if ((rc = upload(&p->d_flags, zeros, &p->bytes_device))) break;
+        }
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
         if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
@@ -686,7 +730,10 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         hipEvent_t e;
         if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); evs.push_back(e); }
     };
-    if (first) HIP_TRY(hipEventRecord(p->ev0, st));
+    if (first) {
+        HIP_TRY(hipEventRecord(p->ev0, st));
+        p->epoch = (p->epoch == 0x7fffffff) ? 1 : p->epoch + 1;     // flag value of this factorization's fused steps (never 0)
+    }
     if (first) {
         HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), st));
         if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
@@ -717,6 +764,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 else sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st);
                 break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
+            case 5: sf::launch_step(p->d_steps + L.first, L.count, p->d_Lsx, p->d_flags, p->epoch, p->d_info, st); break;
             case 2:
             case 3:
             case 4: {
@@ -892,6 +940,7 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     if (k == "last_trsm_ms") return p->last_kind_ms[1];
     if (k == "last_inner_gemm_ms") return p->last_kind_ms[2];
     if (k == "last_outer_gemm_ms") return p->last_kind_ms[4];
+    if (k == "last_step_ms") return p->last_kind_ms[5];
     if (k == "flops_outer_gemm") return p->flops_outer_gemm;
     return -1;
 }

@@ -8,6 +8,7 @@ namespace sf {
 constexpr int NB = 64;          // diagonal block size of the in-panel right-looking factorization
 constexpr int OUTER_NB = 512;      // outer (left-looking) block-column width of the two-level panel factorization
 constexpr int TRSM_ROWS = 256;  // rows per TRSM workgroup (one row per lane)
+constexpr int ST_ROWS = 64;     // rows per workgroup of the fused 64-column step (k_step)
 constexpr int GEMM_BM = 128;    // tile extent along ci (target rows; contiguous in memory)
 constexpr int GEMM_BN = 128;    // tile extent along cj (target columns)
 constexpr int GEMM_BK = 16;
@@ -56,6 +57,14 @@ struct TrsmTask {   // rows [row0, row0+nrows) of panel columns [diag, diag+b) <
     int32_t unit;       // 1: D has an implicit unit diagonal (LU: U12^T <- U12^T * L11^{-T})
 };
 
+struct StepTask {   // fused 64-column step on rows [row0, row0+nrows) of panel columns [diag, diag+b), updated by columns [J, diag)
+    int64_t panel;
+    int32_t ld, J, diag, b;
+    int32_t row0, nrows;    // row0 == diag: the diagonal block (POTRF, publishes `flag`); else rows below it (wait for `flag`)
+    int32_t flag;           // index of this (panel, step)'s flag
+    int32_t pad;
+};
+
 // skip_diag != 0: entries with row == column are not stored (LU: the L panel)
 void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
                         const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
@@ -68,6 +77,9 @@ void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shi
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
                     const double* PL, const double* PU, double* out, int64_t ref_size, hipStream_t st);
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
+// tasks: the diagonal blocks first, then the 64-row tiles below them; at most GEMM_GRID tasks (all resident at once);
+// flags[task.flag] == epoch once that diagonal block is factored
+void launch_step(const StepTask* tasks, int ntasks, double* Lsx, int* flags, int epoch, int* info, hipStream_t st);
 // One-time (plan creation): relative maps of all scatter problems [first, first+count) -- the device form of the
 // reference's createRelativeMap (cuda_kernel.cu:42-60): RelMap[map_off + ci] = position of source row ci in the
 // target supernode's row list.

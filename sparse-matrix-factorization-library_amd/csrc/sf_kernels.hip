@@ -562,6 +562,223 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused 64-column step of the in-panel factorization (Cholesky, latency-bound steps: at most GEMM_GRID
+// workgroups, so that all of them are resident at once).  ONE launch does what used to be three
+// (left-looking update K = 64 t, POTRF of the diagonal block, TRSM of the rows below):
+//   diagonal workgroup (one per panel):   D <- D - Y_D Y_D^T (MFMA) ; D <- chol(D)  (registers of wave 0) ; publish
+//   row workgroups (one per 64 rows):     R <- R - Y_R Y_D^T (MFMA) ; wait for D ; R <- R D^{-T} (blocked, MFMA)
+// The row workgroups' update -- most of the step's work -- runs WHILE the diagonal block is being factored; they
+// pick the factored block up through a per-(panel, step) flag (release store after __threadfence by the diagonal
+// workgroup, acquire load by the waiting one, device scope; the flag value is the factorization's epoch, so flags
+// are never reset).  Diagonal workgroups have the lowest block indices, i.e. they are dispatched first, and the
+// launch never exceeds the number of resident workgroup slots: a waiting workgroup cannot keep the one it waits
+// for off the chip.  The wait is bounded all the same (info = 2 instead of a hang).
+// Every element of the block column is read and written once.  4 waves (2 x 2), each a 32 x 32 sub-tile = 2 x 2
+// v_mfma_f64_16x16x4_f64 tiles; K is short (<= 448), so the MFMA fragments are loaded straight from the panel
+// (16 consecutive rows x 4 k per load), 32 k ahead in registers, no LDS staging and no barriers in the K loop.
+// The updated 64 x 64 tile then goes to LDS (U[column][row]) where the POTRF wave / the blocked solve picks it up.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ST_ULD = ST_ROWS + 1;      // LDS column stride of the updated tile U[c][r]
+constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
+
+__global__ void __launch_bounds__(256, 2)
+k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info) {
+    __shared__ __attribute__((aligned(16))) double U[NB * ST_ULD];
+    __shared__ __attribute__((aligned(16))) double Dt[NB][NB];           // Dt[k][j] = L(j,k), k < j
+    __shared__ double Dinv[NB];
+    static_assert(NB == ST_ROWS && NB == 64, "one wavefront per 64 x 64 tile");
+
+    const StepTask t = tasks[blockIdx.x];
+    const bool is_diag = t.row0 == t.diag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t ld = t.ld;
+    const int b = t.b, nrows = t.nrows;
+    const int nhp = (t.diag - t.J) / NB;             // K = 64 nhp: pairs of 32-deep halves
+    double* __restrict__ Ag = Lsx + t.panel + t.row0 + (int64_t)t.diag * ld;          // this tile: rows row0.., columns diag..
+    const double* __restrict__ Dg = Lsx + t.panel + t.diag + (int64_t)t.diag * ld;   // the diagonal block
+
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    if (nhp > 0) {
+        // fragment rows are clamped into the tile: values of rows beyond nrows / b only reach accumulator entries
+        // that are replaced by the padding below
+        const double* __restrict__ xb = Lsx + t.panel + t.diag + (int64_t)(t.J + fk) * ld;
+        const double* __restrict__ yb = Lsx + t.panel + t.row0 + (int64_t)(t.J + fk) * ld;
+        const double* xq[2];
+        const double* yq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            xq[q] = xb + min(wn * 32 + q * 16 + fr, b - 1);
+            yq[q] = yb + min(wm * 32 + q * 16 + fr, nrows - 1);
+        }
+        double fa[2][8][2], fc[2][8][2];       // [buffer][kk][q]: 32 k per buffer
+        auto load_half = [&](int bufi, int h) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int64_t off = (int64_t)(h * 32 + kk * 4) * ld;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    fa[bufi][kk][q] = xq[q][off];
+                    fc[bufi][kk][q] = yq[q][off];
+                }
+            }
+        };
+        auto mma_half = [&](int bufi) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[bufi][kk][tm], fc[bufi][kk][tn], acc[tm][tn], 0, 0, 0);
+        };
+        load_half(0, 0);
+        for (int hp = 0; hp < nhp; ++hp) {
+            load_half(1, 2 * hp + 1);
+            mma_half(0);
+            if (hp + 1 < nhp) load_half(0, 2 * hp + 2);
+            mma_half(1);
+        }
+    }
+
+    // accumulators -> U[cj][ci] = A(ci, cj) - update (padded with the identity / zeros)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int ci = wm * 32 + tn * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cj = wn * 32 + tm * 16 + fk + 4 * r;
+                double v = (is_diag && ci == cj) ? 1.0 : 0.0;
+                if (ci < nrows && cj < b && (!is_diag || cj <= ci)) v = Ag[ci + (int64_t)cj * ld] - acc[tm][tn][r];
+                U[cj * ST_ULD + ci] = v;
+            }
+        }
+
+    if (is_diag) {
+        __syncthreads();
+        if (wave != 0) return;
+        // POTRF of the updated block: lane r holds row r (see k_potrf_block)
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = U[c * ST_ULD + lane];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double djj = readlane_f64(a[j], j);
+            bad = bad || !(djj > 0.0);
+            double rinv = __builtin_amdgcn_rsq(djj);
+            rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
+            rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
+            const double d = djj * rinv;
+            const double lj = (lane == j) ? d : ((lane > j) ? a[j] * rinv : 0.0);
+            a[j] = lj;
+#pragma unroll
+            for (int c = j + 1; c < NB; ++c) a[c] -= lj * readlane_f64(lj, c);
+        }
+        if (bad && lane == 0) atomicExch(info, 1);
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (lane < b && c <= lane) Ag[lane + (int64_t)c * ld] = a[c];
+        // publish: every lane's stores of the block have left the wave, then ONE device-scope release by lane 0, then
+        // the flag (the explicit waits keep the order whatever the compiler does with the fence's own wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flags + t.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    // wait for this panel's diagonal block of this step
+    if (tid == 0) {
+        int spins = 0;
+        // relaxed polls (an acquire load would invalidate this CU's caches at every iteration, and with hundreds of
+        // waiting workgroups that slows the whole chip down); ONE acquire fence once the flag is seen
+        while (__hip_atomic_load(flags + t.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > ST_SPIN_LIMIT) { atomicExch(info, 2); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int k = e / NB, j = e % NB;
+        Dt[k][j] = (j < b && k < j) ? Dg[j + (int64_t)k * ld] : 0.0;
+    }
+    if (tid < NB) Dinv[tid] = (tid < b) ? 1.0 / Dg[tid + (int64_t)tid * ld] : 1.0;
+    __syncthreads();
+
+    // X <- X D^{-T}, blocked by 16 columns: wave 0 solves the 16 columns of block q by substitution (lane = row),
+    // then every wave updates its 16 rows of the columns to the right with MFMA:
+    //   U[cj][ci] -= sum_k D(cj,k) X(ci,k),  k in block q  (A operand = -Dt, B operand = X from U)
+#pragma unroll 1
+    for (int q = 0; q < NB / 16; ++q) {
+        const int c0 = q * 16;
+        if (c0 >= b) break;
+        if (wave == 0) {
+            // two 8-column register blocks (the shape k_trsm_block uses; a 16-wide block makes the compiler spill)
+#pragma unroll 1
+            for (int jb = c0; jb < c0 + 16; jb += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = U[(jb + u) * ST_ULD + lane];
+                for (int k = c0; k < jb; ++k) {
+                    const double xk = U[k * ST_ULD + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] -= xk * Dt[k][jb + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                    for (int v = 0; v < u; ++v) x[u] -= x[v] * Dt[jb + v][jb + u];
+                    x[u] *= Dinv[jb + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    U[(jb + u) * ST_ULD + lane] = x[u];
+                    if (lane < nrows && jb + u < b) Ag[lane + (int64_t)(jb + u) * ld] = x[u];
+                }
+            }
+        }
+        __syncthreads();
+        if (c0 + 16 < b) {
+            const int ci = wave * 16 + fr;                  // this wave's 16 rows
+            double xf[4];
+#pragma unroll
+            for (int sgm = 0; sgm < 4; ++sgm) xf[sgm] = U[(c0 + 4 * sgm + fk) * ST_ULD + ci];    // B[k][j = ci]
+            for (int ct = q + 1; ct < NB / 16; ++ct) {
+                const int cb = ct * 16;
+                if (cb >= b) break;
+                double4_t d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = U[(cb + fk + 4 * r) * ST_ULD + ci];            // D[i = cj][j = ci]
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm)
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(-Dt[c0 + 4 * sgm + fk][cb + fr], xf[sgm], d, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) U[(cb + fk + 4 * r) * ST_ULD + ci] = d[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_step(const StepTask* tasks, int ntasks, double* Lsx, int* flags, int epoch, int* info, hipStream_t st) {
+    if (ntasks <= 0) return;
+    hipLaunchKernelGGL(k_step, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info);
+}
+
 // relative map of every scatter problem: one workgroup per problem, lanes stride over its M source rows
 __global__ void __launch_bounds__(256)
 k_build_relmaps(const GemmProb* __restrict__ probs, const int32_t* __restrict__ Lsi, int32_t* __restrict__ RelMap) {

@@ -1,0 +1,62 @@
+// Stand-alone timing of the fused 64-column step kernel (k_step) on a synthetic panel.
+//   hipcc -O3 --offload-arch=gfx950 -Isparse-matrix-factorization-library_amd/csrc -Iinclude tools/step_bench.hip \
+//         -Lsparse-matrix-factorization-library_amd -lsparseframe_hip -Wl,-rpath,$PWD/sparse-matrix-factorization-library_amd -o /tmp/step_bench
+//   /tmp/step_bench            (table: tasks x ti)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "sf_kernels.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main() {
+    const int nscol = 512;
+    const int64_t nsrow = 64 * 8192 + 512;        // up to 8192 row tiles
+    double* d;
+    CK(hipMalloc(&d, ((size_t)nsrow * nscol + 2) * sizeof(double)));
+    {
+        std::vector<double> h((size_t)nsrow);
+        for (int c = 0; c < nscol; ++c) {
+            for (int64_t r = 0; r < nsrow; ++r) h[r] = (r == c) ? 8.0 : ((double)rand() / RAND_MAX - 0.5) * 1e-2;
+            CK(hipMemcpy(d + (size_t)c * nsrow, h.data(), nsrow * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    int* info;
+    CK(hipMalloc(&info, sizeof(int)));
+    CK(hipMemset(info, 0, sizeof(int)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    sf::StepTask* dt;
+    CK(hipMalloc(&dt, 8192 * sizeof(sf::StepTask)));
+    int* flags;
+    CK(hipMalloc(&flags, sizeof(int)));
+    CK(hipMemset(flags, 0, sizeof(int)));
+    int epoch = 0;
+    printf("row-tiles ti   us/launch   (one diagonal workgroup + row tiles, one k_step launch)\n");
+    for (int ntiles : {0, 1, 64, 207, 414, 511}) {
+        for (int ti : {0, 1, 3, 7}) {
+            std::vector<sf::StepTask> t;
+            const int diag = 64 * ti;
+            t.push_back(sf::StepTask{0, (int32_t)nsrow, 0, diag, 64, diag, 64, 0, 0});
+            for (int k = 0; k < ntiles; ++k) t.push_back(sf::StepTask{0, (int32_t)nsrow, 0, diag, 64, 512 + 64 * k, 64, 0, 0});
+            CK(hipMemcpy(dt, t.data(), t.size() * sizeof(sf::StepTask), hipMemcpyHostToDevice));
+            const int reps = 20;
+            sf::launch_step(dt, (int)t.size(), d, flags, ++epoch, info, 0);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            for (int r = 0; r < reps; ++r) sf::launch_step(dt, (int)t.size(), d, flags, ++epoch, info, 0);
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%5d      %d   %8.1f\n", ntiles, ti, ms * 1e3 / reps);
+        }
+    }
+    int hinfo = 0;
+    CK(hipMemcpy(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost));
+    printf("info %d (repeated in-place steps on the same data: 1 = pivot breakdown is expected here, 2 = flag wait timed out)\n", hinfo);
+    return 0;
+}
