@@ -533,8 +533,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     solve.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, std::min(sf::NB, nscol - diag), 0, 0, (int32_t)Super[s]});
                 }
                 st.diag_count = (int)(solve.size() - st.diag_first);
-                for (int dir = 0; dir < 2; ++dir) {         // 0: forward tiles of 256 rows, 1: backward tiles of 1024 rows
-                    const int tile = dir ? 1024 : 256;
+                for (int dir = 0; dir < 2; ++dir) {         // 0: forward, 1: backward; tiles of 256 rows
+                    const int tile = 256;
                     const int64_t first = (int64_t)solve.size();
                     for (sf_long s : by_level[l]) {
                         const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);

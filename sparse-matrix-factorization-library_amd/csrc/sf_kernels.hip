@@ -302,23 +302,35 @@ k_solve_fwd_update(const SolveTask* __restrict__ tasks, const double* __restrict
     unsafeAtomicAdd(x + Lsi[t.rows + r], -acc);
 }
 
-// one workgroup per tile of up to 1024 rows; wave w sums columns w, w+4, ... of the block over the tile's rows
+// one workgroup per tile of up to 256 rows; wave w sums columns 16 w .. 16 w + 15 of the block over the tile's rows,
+// four columns at a time (independent loads in flight), one atomic per column
 __global__ void __launch_bounds__(256)
 k_solve_bwd_update(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
                    double* __restrict__ x) {
-    __shared__ double xr[1024];
+    __shared__ double xr[256];
     const SolveTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < t.nrows; i += 256) xr[i] = x[Lsi[t.rows + t.row0 + i]];
+    xr[tid] = (tid < t.nrows) ? x[Lsi[t.rows + t.row0 + tid]] : 0.0;
     __syncthreads();
     const double* Lt = Lsx + t.panel + t.row0 + (int64_t)t.diag * t.ld;
-    for (int c = wave; c < t.b; c += 4) {
-        const double* col = Lt + (int64_t)c * t.ld;
-        double acc = 0.0;
-        for (int i = lane; i < t.nrows; i += 64) acc += col[i] * xr[i];
+    for (int c0 = wave * 16; c0 < min(wave * 16 + 16, t.b); c0 += 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) unsafeAtomicAdd(x + t.first_col + t.diag + c, -acc);
+        for (int u = 0; u < 4; ++u) {
+            const double* col = Lt + (int64_t)min(c0 + u, t.b - 1) * t.ld;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                acc[u] += ((i < t.nrows) ? col[i] : 0.0) * xr[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double v = acc[u];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && c0 + u < t.b) unsafeAtomicAdd(x + t.first_col + t.diag + c0 + u, -v);
+        }
     }
 }
 
@@ -580,114 +592,160 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 // The updated 64 x 64 tile then goes to LDS (U[column][row]) where the POTRF wave / the blocked solve picks it up.
 // ---------------------------------------------------------------------------------------------------
 constexpr int ST_ULD = ST_ROWS + 1;      // LDS column stride of the updated tile U[c][r]
+constexpr int ST_KC = 32;                // K chunk of the update's LDS-staged operand
+constexpr int ST_XLD = ST_ROWS + 16;     // its LDS row stride
 constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 
 __global__ void __launch_bounds__(256, 2)
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info) {
-    __shared__ __attribute__((aligned(16))) double U[NB * ST_ULD];
-    __shared__ __attribute__((aligned(16))) double Dt[NB][NB];           // Dt[k][j] = L(j,k), k < j
+    // one LDS array: U[c][r] (updated tile) | Dt[k][j] = L(j,k), k < j (rows path); the X staging buffers of the
+    // update alias both (they are dead before U / Dt are written)
+    __shared__ __attribute__((aligned(16))) double smem[NB * ST_ULD + NB * NB];
     __shared__ double Dinv[NB];
     static_assert(NB == ST_ROWS && NB == 64, "one wavefront per 64 x 64 tile");
+    static_assert(2 * ST_KC * ST_XLD <= NB * ST_ULD + NB * NB, "X staging buffers must fit");
+    double* __restrict__ U = smem;
+    double (*Dt)[NB] = reinterpret_cast<double (*)[NB]>(smem + NB * ST_ULD);
 
     const StepTask t = tasks[blockIdx.x];
     const bool is_diag = t.row0 == t.diag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 15, fk = lane >> 4;
     const int64_t ld = t.ld;
     const int b = t.b, nrows = t.nrows;
-    const int nhp = (t.diag - t.J) / NB;             // K = 64 nhp: pairs of 32-deep halves
+    const int nhp = (t.diag - t.J) / NB;             // K = 64 nhp = 2 nhp chunks of ST_KC = 32
     double* __restrict__ Ag = Lsx + t.panel + t.row0 + (int64_t)t.diag * ld;          // this tile: rows row0.., columns diag..
     const double* __restrict__ Dg = Lsx + t.panel + t.diag + (int64_t)t.diag * ld;   // the diagonal block
 
-    double4_t acc[2][2];
+    // Update: wave w owns rows 16 w .. 16 w + 15 of the tile x all 64 columns (4 MFMA tiles).  Its own rows' fragments
+    // (B operand) come straight from the panel, one chunk ahead in registers -- each element is loaded once; the
+    // diagonal block's rows (A operand, shared by the 4 waves) go through LDS in 32-deep chunks, staged like k_gemm
+    // (16-byte row-pair loads, [k][row] image, double-buffered, one barrier per chunk).
+    double4_t acc[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[a][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < 4; ++a) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     if (nhp > 0) {
-        // fragment rows are clamped into the tile: values of rows beyond nrows / b only reach accumulator entries
-        // that are replaced by the padding below
-        const double* __restrict__ xb = Lsx + t.panel + t.diag + (int64_t)(t.J + fk) * ld;
-        const double* __restrict__ yb = Lsx + t.panel + t.row0 + (int64_t)(t.J + fk) * ld;
-        const double* xq[2];
-        const double* yq[2];
+        double (*Xs)[ST_KC][ST_XLD] = reinterpret_cast<double (*)[ST_KC][ST_XLD]>(smem);
+        const int nch = 2 * nhp;
+        const int prow = 2 * (tid & 31), pk0 = tid >> 5;       // row pair, k = pk0 + 8 q
+        // rows beyond b / nrows are clamped: their values only reach accumulator entries replaced by the padding below
+        const double* __restrict__ xp = Lsx + t.panel + t.diag + (int64_t)t.J * ld + ((prow < b) ? prow : 0);
+        const double* __restrict__ yp = Lsx + t.panel + t.row0 + (int64_t)(t.J + fk) * ld + min(16 * wave + fr, nrows - 1);
+        double2_t rx[4];
+        double fy[2][8];
+        auto load_x = [&](int h) {
+            const int hc = min(h, nch - 1);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            xq[q] = xb + min(wn * 32 + q * 16 + fr, b - 1);
-            yq[q] = yb + min(wm * 32 + q * 16 + fr, nrows - 1);
-        }
-        double fa[2][8][2], fc[2][8][2];       // [buffer][kk][q]: 32 k per buffer
-        auto load_half = [&](int bufi, int h) {
+            for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const double2_t*>(xp + (int64_t)(hc * ST_KC + pk0 + 8 * q) * ld);
+        };
+        auto store_x = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2_t*>(&Xs[buf][pk0 + 8 * q][prow]) = rx[q];
+        };
+        auto load_y = [&](int bufi, int h) {
+            const int hc = min(h, nch - 1);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) fy[bufi][kk] = yp[(int64_t)(hc * ST_KC + 4 * kk) * ld];
+        };
+        auto compute = [&](int buf, int h) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                const int64_t off = (int64_t)(h * 32 + kk * 4) * ld;
+                double a[4];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    fa[bufi][kk][q] = xq[q][off];
-                    fc[bufi][kk][q] = yq[q][off];
-                }
+                for (int q = 0; q < 4; ++q) a[q] = Xs[buf][4 * kk + fk][16 * q + fr];
+                if (kk == 0) store_x(buf ^ 1);
+                if (kk == 1) load_x(h + 2);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], fy[buf][kk], acc[q], 0, 0, 0);
             }
         };
-        auto mma_half = [&](int bufi) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[bufi][kk][tm], fc[bufi][kk][tn], acc[tm][tn], 0, 0, 0);
-        };
-        load_half(0, 0);
+        load_x(0);
+        load_y(0, 0);
+        store_x(0);
+        __syncthreads();
+        load_x(1);
         for (int hp = 0; hp < nhp; ++hp) {
-            load_half(1, 2 * hp + 1);
-            mma_half(0);
-            if (hp + 1 < nhp) load_half(0, 2 * hp + 2);
-            mma_half(1);
+            load_y(1, 2 * hp + 1);
+            compute(0, 2 * hp);
+            __syncthreads();
+            load_y(0, 2 * hp + 2);
+            compute(1, 2 * hp + 1);
+            __syncthreads();
         }
     }
 
-    // accumulators -> U[cj][ci] = A(ci, cj) - update (padded with the identity / zeros)
+    // accumulators -> U[cj][ci] = A(ci, cj) - update (padded with the identity / zeros); the staging buffers are dead
+    // (the chunk loop ends with a barrier)
+    {
+        const int ci = 16 * wave + fr;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int ci = wm * 32 + tn * 16 + fr;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int cj = wn * 32 + tm * 16 + fk + 4 * r;
+                const int cj = 16 * q + fk + 4 * r;
                 double v = (is_diag && ci == cj) ? 1.0 : 0.0;
-                if (ci < nrows && cj < b && (!is_diag || cj <= ci)) v = Ag[ci + (int64_t)cj * ld] - acc[tm][tn][r];
+                if (ci < nrows && cj < b && (!is_diag || cj <= ci)) v = Ag[ci + (int64_t)cj * ld] - acc[q][r];
                 U[cj * ST_ULD + ci] = v;
             }
-        }
+    }
 
     if (is_diag) {
         __syncthreads();
-        if (wave != 0) return;
-        // POTRF of the updated block: lane r holds row r (see k_potrf_block)
-        double a[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = U[c * ST_ULD + lane];
+        // POTRF of the updated block, blocked by 16 columns.  Panel part: wave 0, lane r holds row r of the 16 columns
+        // (k_potrf_block's scheme; the column scaling of all 64 rows comes with it, so there is no separate TRSM).
+        // Trailing part: every wave updates its 16 rows of the columns to the right with MFMA out of LDS,
+        //   U[cj][ci] -= sum_k L(cj,k) L(ci,k),  k in the panel  (A operand = -L rows cj, B operand = L rows ci)
         bool bad = false;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double djj = readlane_f64(a[j], j);
-            bad = bad || !(djj > 0.0);
-            double rinv = __builtin_amdgcn_rsq(djj);
-            rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
-            rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
-            const double d = djj * rinv;
-            const double lj = (lane == j) ? d : ((lane > j) ? a[j] * rinv : 0.0);
-            a[j] = lj;
+        for (int q = 0; q < NB / 16; ++q) {
+            const int c0 = q * 16;
+            if (wave == 0) {
+                double a[16];
 #pragma unroll
-            for (int c = j + 1; c < NB; ++c) a[c] -= lj * readlane_f64(lj, c);
+                for (int u = 0; u < 16; ++u) a[u] = U[(c0 + u) * ST_ULD + lane];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double djj = readlane_f64(a[j], c0 + j);
+                    bad = bad || !(djj > 0.0);
+                    double rinv = __builtin_amdgcn_rsq(djj);
+                    rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
+                    rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
+                    const double d = djj * rinv;
+                    const double lj = (lane == c0 + j) ? d : ((lane > c0 + j) ? a[j] * rinv : 0.0);
+                    a[j] = lj;
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) a[c] -= lj * readlane_f64(lj, c0 + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    U[(c0 + u) * ST_ULD + lane] = a[u];
+                    if (lane < b && c0 + u <= lane) Ag[lane + (int64_t)(c0 + u) * ld] = a[u];
+                }
+            }
+            if (q == NB / 16 - 1) break;
+            __syncthreads();
+            if (wave > q) {
+                const int ci = wave * 16 + fr;                  // this wave's 16 rows
+                double lf[4];
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) lf[sgm] = U[(c0 + 4 * sgm + fk) * ST_ULD + ci];            // B[k][j = ci]
+                for (int ct = q + 1; ct <= wave; ++ct) {
+                    const int cb = ct * 16;
+                    double4_t d;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[r] = U[(cb + fk + 4 * r) * ST_ULD + ci];                    // D[i = cj][j = ci]
+#pragma unroll
+                    for (int sgm = 0; sgm < 4; ++sgm)
+                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(c0 + 4 * sgm + fk) * ST_ULD + cb + fr], lf[sgm], d, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) U[(cb + fk + 4 * r) * ST_ULD + ci] = d[r];
+                }
+            }
+            __syncthreads();
         }
+        if (wave != 0) return;
         if (bad && lane == 0) atomicExch(info, 1);
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-            if (lane < b && c <= lane) Ag[lane + (int64_t)c * ld] = a[c];
         // publish: every lane's stores of the block have left the wave, then ONE device-scope release by lane 0, then
         // the flag (the explicit waits keep the order whatever the compiler does with the fence's own wait)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
