@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from util import sf, gen, nd_perm_py, small_cases, rel_err
+from util import sf, gen, nd_perm_py, small_cases, wide_cases, rel_err
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -36,6 +36,26 @@ def test_factor_matches_oracle(oracle, case):
     assert rel_err(Lsx, ref, mask) <= TOL_FACTOR
     res, _ = oracle.chol_residual(sym, Lsx)
     assert res <= TOL_RESIDUAL
+    plan.close()
+
+
+@pytest.mark.parametrize("case", wide_cases(), ids=lambda c: c[0])
+def test_wide_supernodes_match_oracle(oracle, case):
+    """multi-step panels through the fused 64-column step kernel (k_step) and the blocked outer GEMMs"""
+    name, n, Cp, Ci, Cx, perm, slot = case
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    assert np.diff(sym.Super).max() > 64
+    plan, Lsx = gpu_factor(sym)
+    assert plan.stat("last_step_ms") >= 0                 # stat exists; the fused path is part of this plan
+    ref, info, _ = oracle.chol_factorize(sym)
+    assert info == 0
+    assert rel_err(Lsx, ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+    res, _ = oracle.chol_residual(sym, Lsx)
+    assert res <= TOL_RESIDUAL
+    # device solve on the same factor
+    b = 1.0 + np.arange(n) / n
+    x = plan.solve(b)
+    assert sf.validate_solution(sym, x, b) <= 1e-12
     plan.close()
 
 

@@ -104,6 +104,50 @@ def small_cases():
     return cases
 
 
+def _dense_lower_csc(A):
+    nd_ = A.shape[0]
+    rows, cols = np.tril_indices(nd_)
+    keep = A[rows, cols] != 0.0
+    rows, cols = rows[keep], cols[keep]
+    order = np.lexsort((rows, cols))
+    rows, cols = rows[order], cols[order]
+    Cp = np.zeros(nd_ + 1, dtype=np.int64)
+    np.add.at(Cp, cols + 1, 1)
+    return nd_, np.cumsum(Cp), rows.astype(np.int64), A[rows, cols]
+
+
+def wide_cases():
+    """wide supernodes: several 512-column outer blocks / 64-column steps per panel, last blocks narrower than 64,
+    panels without rows below, several panels of different widths in one level (the fused-step launches and their
+    per-panel flags), dense tails with many contributing descendants"""
+    rng = np.random.default_rng(11)
+    cases = []
+
+    def spd(n_):
+        A = rng.uniform(-1, 1, (n_, n_))
+        return A @ A.T + n_ * np.eye(n_)
+
+    cases.append(("dense_700",) + _dense_lower_csc(spd(700)) + (None, 1 << 30))
+    sizes = (130, 64, 65, 200, 1, 513)
+    n_ = sum(sizes)
+    A = np.zeros((n_, n_))
+    o = 0
+    for k in sizes:
+        A[o:o + k, o:o + k] = spd(k)
+        o += k
+    cases.append(("blockdiag_dense",) + _dense_lower_csc(A) + (None, 1 << 30))
+    n_, w = 1000, 150                                     # dense band: a chain of wide panels with rows below
+    A = rng.uniform(-1, 1, (n_, n_))
+    A = (A + A.T) / 2
+    i, j = np.indices((n_, n_))
+    A[np.abs(i - j) > w] = 0.0
+    A[i == j] = 2 * w + 2.0                               # strictly diagonally dominant
+    cases.append(("band_dense_1000_150",) + _dense_lower_csc(A) + (None, 1 << 30))
+    n_, Cp, Ci, Cx = gen.arrow_spd_lower(900, 200)        # sparse head, dense 200-column tail
+    cases.append(("arrow_900_200", n_, Cp, Ci, Cx, None, 1 << 30))
+    return cases
+
+
 def dense_reference_factor(sym):
     """dense LAPACK Cholesky of the permuted matrix described by (Lp, Li, Lx)"""
     n = sym.n if not isinstance(sym, dict) else sym["n"]
