@@ -53,6 +53,9 @@ def main():
                     help="N > 1 with --mp subtree*: weak = grid round(base * N^(1/6)) (flops per GPU fixed), strong = base grid")
     ap.add_argument("--check", action="store_true", help="download the factor and check the residual on the host")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pcie", action="store_true",
+                    help="N = 1: also time the host-buffer boundary (values H2D + factorize + factor D2H, what the struct "
+                         "entry point SparseFrame_factorize does per call) and report it in config.pcie_inclusive; never `value`")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,10 +73,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
+        import datetime
+        tmo = datetime.timedelta(seconds=600)            # a rank that dies must not leave the others waiting for long
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     ngpu = max(args.gpus, 1)
     if world != ngpu and world > 1:
         raise SystemExit(f"--gpus {ngpu} but WORLD_SIZE={world}")
@@ -207,6 +212,25 @@ def main():
         xs = plan.solve(1 + np.arange(n) / n)
         out["config"]["residual_device_solve"] = sf.validate_solution(sym, xs)
         out["config"]["device_solve_ms"] = round(plan.stat("last_solve_ms"), 3)
+
+    if args.pcie and rank == 0 and sharded is None:
+        host = np.empty(max(sym.xsize, 1), dtype=np.float64)
+        host[:] = 0.0                                    # touch the pages: first-touch faults are not PCIe time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if lu:
+            plan.set_values(sym.Lx, sym.Ux)
+        else:
+            plan.set_values(sym.Lx)
+        plan.factorize(sync=True)
+        t1 = time.perf_counter()
+        plan.get_factor(host)
+        t2 = time.perf_counter()
+        out["config"]["pcie_inclusive"] = {"ms": round((t2 - t0) * 1e3, 1), "factor_download_ms": round((t2 - t1) * 1e3, 1),
+                                           "factor_bytes": int(sym.xsize) * 8,
+                                           "GFLOPs": round(F_struct / (t2 - t0) / 1e9, 1),
+                                           "note": "pageable host memory; upload of the values + factorize + download of the factor"}
+        del host
 
     if args.check and sharded is not None:
         import oracle
