@@ -166,6 +166,11 @@ sf_long sf_chol_plan_num_segments(const sf_chol_plan *plan);
 /* offsets/counts may be NULL to query *nregions only */
 int sf_chol_plan_segment_regions(const sf_chol_plan *plan, sf_long k, sf_long capacity, sf_long *nregions,
                                  sf_long *offsets, sf_long *counts);
+/* alternative to reducing the regions in place: gather the part of segment k's regions that can be non-zero (rows from
+ * each block's first column down) into ONE contiguous device buffer; all-reduce(sum) *device_ptr[0 .. *count) and call
+ * sf_chol_plan_factorize_segment(plan, k), which scatters it back first.  One collective per segment and the
+ * structurally zero rows above the blocks' diagonals (half of a square root panel) stay off the wire. */
+int sf_chol_plan_segment_pack(sf_chol_plan *plan, sf_long k, void **device_ptr, sf_long *count);
 int sf_chol_plan_factorize_segment(sf_chol_plan *plan, sf_long k, int sync);
 int sf_chol_plan_set_stream(sf_chol_plan *plan, void *hip_stream);
 

@@ -108,6 +108,8 @@ lib.sf_chol_plan_num_segments.argtypes = [C.c_void_p]
 lib.sf_chol_plan_num_segments.restype = C.c_int64
 lib.sf_chol_plan_segment_regions.argtypes = [C.c_void_p, C.c_int64, C.c_int64, c_long_p, c_long_p, c_long_p]
 lib.sf_chol_plan_segment_regions.restype = C.c_int
+lib.sf_chol_plan_segment_pack.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_long_p]
+lib.sf_chol_plan_segment_pack.restype = C.c_int
 lib.sf_chol_plan_factorize_segment.argtypes = [C.c_void_p, C.c_int64, C.c_int]
 lib.sf_chol_plan_factorize_segment.restype = C.c_int
 lib.sf_chol_plan_set_stream.argtypes = [C.c_void_p, C.c_void_p]

@@ -223,6 +223,13 @@ class CholPlan:
               "sf_chol_plan_segment_regions")
         return [(int(off[i]), int(cnt[i])) for i in range(nr.value)]
 
+    def segment_pack(self, k):
+        """gather segment k's possibly non-zero block parts into the plan's contiguous scratch buffer (enqueued on the
+        plan's stream); returns (device pointer, number of doubles) to all-reduce before factorize_segment(k)"""
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        check(lib.sf_chol_plan_segment_pack(self._h, k, C.byref(ptr), C.byref(cnt)), "sf_chol_plan_segment_pack")
+        return ptr.value or 0, cnt.value
+
     def factorize_segment(self, k, sync=False):
         check(lib.sf_chol_plan_factorize_segment(self._h, k, 1 if sync else 0), "sf_chol_plan_factorize_segment")
 

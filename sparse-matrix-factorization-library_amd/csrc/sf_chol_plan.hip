@@ -55,7 +55,11 @@ struct Launch {
 // Schur updates, split outer GEMMs), so its true value is the sum of the ranks' copies.
 struct Segment {
     size_t l0 = 0, l1 = 0;                 // launches [l0, l1)
-    std::vector<int64_t> off, cnt;         // doubles, relative to the factor base pointer
+    std::vector<int64_t> off, cnt;         // whole block columns: doubles, relative to the factor base pointer
+    // the part of each region that can be non-zero (rows >= the block's first column): `cols` pieces of `rows` doubles,
+    // `ld` apart, starting at `src` -- what sf_chol_plan_segment_pack gathers into one contiguous buffer
+    std::vector<int64_t> src, rows, cols, ld;
+    int64_t packed = 0;                    // doubles in the packed buffer
 };
 
 #define HIP_TRY(expr)                                                                       \
@@ -97,6 +101,8 @@ struct sf_chol_plan {
     size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
     int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
     std::vector<Segment> segments;
+    double* d_scratch = nullptr;   // packed segment buffer (max over the segments)
+    int64_t packed_pending = -1;   // segment whose packed buffer has to be scattered back before it runs
     bool own_stream = true;
     int8_t* d_loadmask = nullptr;
     // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
@@ -181,7 +187,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_probs, p->d_gtasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x, p->d_relmap};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x, p->d_relmap, p->d_scratch};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -379,8 +385,14 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 for (sf_long s : Sl) {
                     const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
                     if (J >= nscol) continue;
+                    const int64_t w = std::min<int64_t>(sf::OUTER_NB, nscol - J);
                     sg.off.push_back(XP[s] + (int64_t)J * nsrow);
-                    sg.cnt.push_back(std::min<int64_t>(sf::OUTER_NB, nscol - J) * nsrow);
+                    sg.cnt.push_back(w * nsrow);
+                    sg.src.push_back(XP[s] + (int64_t)J * nsrow + J);
+                    sg.rows.push_back(nsrow - J);
+                    sg.cols.push_back(w);
+                    sg.ld.push_back(nsrow);
+                    sg.packed += (nsrow - J) * w;
                 }
                 p->segments.push_back(std::move(sg));
             }
@@ -633,6 +645,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (lu || p->partial) {
             if ((rc = upload(&p->d_Xp, XP, &p->bytes_device))) break;
         }
+        if (!p->segments.empty()) {
+            int64_t mx = 1;
+            for (const Segment& sg : p->segments) mx = std::max(mx, sg.packed);
+            if (hipMalloc((void**)&p->d_scratch, mx * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += mx * sizeof(double);
+        }
         if (p->partial) {
             std::vector<int8_t> mask(std::max<sf_long>(nsuper, 1), 0);
             for (sf_long s = 0; s < nsuper; ++s) mask[s] = (p->phase[s] == 0 || (p->phase[s] == 1 && load_top)) ? 1 : 0;
@@ -732,6 +750,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
     };
     if (first) {
         HIP_TRY(hipEventRecord(p->ev0, st));
+        p->packed_pending = -1;
         p->epoch = (p->epoch == 0x7fffffff) ? 1 : p->epoch + 1;     // flag value of this factorization's fused steps (never 0)
     }
     if (first) {
@@ -836,9 +855,40 @@ int sf_chol_plan_segment_regions(const sf_chol_plan* p, sf_long k, sf_long capac
     return SF_OK;
 }
 
+// gather the possibly non-zero part of segment k's regions into one contiguous buffer (strided device copies on
+// the plan's stream): ONE all-reduce per segment, and the structurally zero rows above each block's diagonal
+// (half of a square root panel) stay off the wire
+int sf_chol_plan_segment_pack(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count) {
+    if (!p || k < 0 || k >= (sf_long)p->segments.size() || !dptr || !count) return SF_ERR_ARG;
+    if (p->packed_pending >= 0) return SF_ERR_ARG;           // the previous packed segment has not been run
+    HIP_TRY(hipSetDevice(p->device));
+    const Segment& sg = p->segments[k];
+    int64_t pos = 0;
+    for (size_t i = 0; i < sg.src.size(); ++i) {
+        HIP_TRY(hipMemcpy2DAsync(p->d_scratch + pos, sg.rows[i] * sizeof(double), p->d_Lsx + sg.src[i], sg.ld[i] * sizeof(double),
+                                 sg.rows[i] * sizeof(double), sg.cols[i], hipMemcpyDeviceToDevice, p->stream));
+        pos += sg.rows[i] * sg.cols[i];
+    }
+    p->packed_pending = k;
+    *dptr = (void*)p->d_scratch;
+    *count = sg.packed;
+    return SF_OK;
+}
+
 int sf_chol_plan_factorize_segment(sf_chol_plan* p, sf_long k, int sync) {
     if (!p || k < 0 || k >= (sf_long)p->segments.size()) return SF_ERR_ARG;
     const Segment& sg = p->segments[k];
+    if (p->packed_pending >= 0) {
+        if (p->packed_pending != k) return SF_ERR_ARG;
+        HIP_TRY(hipSetDevice(p->device));
+        int64_t pos = 0;
+        for (size_t i = 0; i < sg.src.size(); ++i) {
+            HIP_TRY(hipMemcpy2DAsync(p->d_Lsx + sg.src[i], sg.ld[i] * sizeof(double), p->d_scratch + pos, sg.rows[i] * sizeof(double),
+                                     sg.rows[i] * sizeof(double), sg.cols[i], hipMemcpyDeviceToDevice, p->stream));
+            pos += sg.rows[i] * sg.cols[i];
+        }
+        p->packed_pending = -1;
+    }
     return run_launches(p, sg.l0, sg.l1, false, k + 1 == (sf_long)p->segments.size(), sync);
 }
 

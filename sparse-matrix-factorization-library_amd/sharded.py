@@ -5,7 +5,8 @@ CPU tests) of top-panel regions.  Two ways of handling the top supernodes (those
 mode "distributed" (default for world > 1)
     phase 0       every rank assembles and factorizes its own subtrees; their Schur updates into the top panels
                   accumulate in the rank's own copy (zero-initialised except on rank 0, which holds the matrix entries)
-    per segment   (one per top level and 512-column block) all-reduce(sum) of that block of the level's panels, then
+    per segment   (one per top level and 512-column block) all-reduce(sum) of that block of the level's panels (its
+                  rows from the block's first column down, packed into one buffer: one collective per segment), then
                   the block's sequential 64-column POTRF/TRSM chain on every rank (replicated: latency-bound), then this
                   rank's 1/world share of the large GEMMs that follow (next block's left-looking GEMM, the level's
                   Schur updates) -- additive, so any split is valid and nothing is exchanged until the target
@@ -71,9 +72,15 @@ class HipEngine:
         return self.plan.num_segments()
 
     def segment_tensors(self, k):
-        if k not in self._seg:
-            self._seg[k] = [self._alias(o, c) for (o, c) in self.plan.segment_regions(k) if c > 0]
-        return self._seg[k]
+        """tensors to sum over the ranks before factorize_segment(k): ONE packed buffer per segment (the blocks' rows from
+        their first column down; the structurally zero rows above stay off the wire), gathered on the plan's stream"""
+        import torch
+        ptr, cnt = self.plan.segment_pack(k)
+        if cnt <= 0:
+            return []
+        if k not in self._seg or self._seg[k][0] != (ptr, cnt):
+            self._seg[k] = ((ptr, cnt), torch.as_tensor(_DevArray(ptr, cnt), device=f"cuda:{self.device}"))
+        return [self._seg[k][1]]
 
     def factorize_segment(self, k):
         self.plan.factorize_segment(k, sync=False)

@@ -37,8 +37,7 @@ def main():
     eng = sharded.HipEngine(sym, sf.phases_for_rank(owner, args.rank), args.rank == 0, 0, args.rank, W, True)
     eng.set_values(sym.Lx)
     nseg = eng.num_segments()
-    top_doubles = sum(c for k in range(nseg) for (_, c) in eng.plan.segment_regions(k))
-    ncalls = sum(len(eng.plan.segment_regions(k)) for k in range(nseg))
+    full_doubles = sum(c for k in range(nseg) for (_, c) in eng.plan.segment_regions(k))
 
     def run():
         torch.cuda.synchronize()
@@ -46,11 +45,13 @@ def main():
         eng.factorize_phase(0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        packed = 0
         for k in range(nseg):
+            packed += sum(t.numel() for t in eng.segment_tensors(k))     # pack (as in a real run), no all-reduce
             eng.factorize_segment(k)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        return (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        return (t1 - t0) * 1e3, (t2 - t1) * 1e3, packed
 
     run()
     res = [run() for _ in range(args.steps)]
@@ -58,7 +59,7 @@ def main():
     p1 = min(r[1] for r in res)
     print(json.dumps({"grid": g, "world": W, "rank": args.rank, "F_struct": sym.flops_struct,
                       "phase0_ms": round(p0, 2), "segments_ms": round(p1, 2), "segments": nseg,
-                      "allreduce_calls": ncalls, "top_bytes": 8 * top_doubles,
+                      "allreduce_calls": nseg, "allreduce_bytes": 8 * res[0][2], "top_panel_bytes": 8 * full_doubles,
                       "top_flop_fraction": tf, "max_rank_subtree_flop_fraction": ml,
                       "stored_doubles": eng.plan.stat("stored_doubles")}))
     eng.close()
