@@ -407,11 +407,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 int64_t step_wgs = 0;
                 for (sf_long s : Sl) {
                     const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
-                    if (diag < nscol) step_wgs += 1 + (nsrow - std::min<int64_t>(nscol, diag + sf::NB) + sf::ST_ROWS - 1) / sf::ST_ROWS;
+                    if (diag < nscol) step_wgs += 1 + (lu ? 2 : 1) * ((nsrow - std::min<int64_t>(nscol, diag + sf::NB) + sf::ST_ROWS - 1) / sf::ST_ROWS);
                 }
-                if (!lu && step_wgs <= sf::GEMM_GRID) {
-                    // Cholesky, latency-bound step (all its workgroups resident at once): the (update, POTRF, TRSM)
-                    // triple is ONE launch of k_step.  Steps with more tiles are throughput-bound and keep the three
+                if (step_wgs <= sf::GEMM_GRID) {
+                    // latency-bound step (all its workgroups resident at once): the (update, POTRF / GETRF, TRSM) triple
+                    // is ONE launch of k_step.  Steps with more tiles are throughput-bound and keep the three
                     // launches (stream-K GEMM over all tiles, 256-row TRSM workgroups).
                     const int64_t d0 = (int64_t)steps.size();
                     std::vector<int32_t> flag_of;
@@ -420,8 +420,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         if (diag >= nscol) { flag_of.push_back(-1); continue; }
                         const int b = std::min(sf::NB, nscol - diag);
                         flag_of.push_back(n_flags);
-                        steps.push_back(StepTask{XP[s], nsrow, J, diag, b, diag, b, n_flags++, 0});
-                        if (ti > 0) p->flops_panel_gemm += (double)b * (b + 1) * (diag - J) + 2.0 * (nsrow - diag - b) * (double)b * (diag - J);
+                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, J, diag, b, diag, b, n_flags++, 0});
+                        if (ti > 0) p->flops_panel_gemm += (lu ? 2.0 : 1.0) * ((double)b * (b + 1) * (diag - J) + 2.0 * (nsrow - diag - b) * (double)b * (diag - J));
                     }
                     size_t si = 0;
                     for (sf_long s : Sl) {
@@ -429,8 +429,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         const int32_t fl = flag_of[si++];
                         if (fl < 0) continue;
                         const int b = std::min(sf::NB, nscol - diag);
-                        for (int r = diag + b; r < nsrow; r += sf::ST_ROWS)
-                            steps.push_back(StepTask{XP[s], nsrow, J, diag, b, r, std::min(sf::ST_ROWS, nsrow - r), fl, 0});
+                        for (int r = diag + b; r < nsrow; r += sf::ST_ROWS) {
+                            const int nr = std::min(sf::ST_ROWS, nsrow - r);
+                            if (!lu) {
+                                steps.push_back(StepTask{XP[s], XP[s], nsrow, J, diag, b, r, nr, fl, 0});
+                            } else {
+                                steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, diag, b, r, nr, fl, 0});     // L21 <- (L21 - ..) U11^{-1}
+                                steps.push_back(StepTask{XP[s] + ushift, XP[s], nsrow, J, diag, b, r, nr, fl, 1});     // U12^T <- (U12^T - ..) L11^{-T}
+                            }
+                        }
                     }
                     if ((int64_t)steps.size() > d0) p->launches.push_back(Launch{5, d0, (int)(steps.size() - d0)});
                     continue;
@@ -783,7 +790,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 else sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st);
                 break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
-            case 5: sf::launch_step(p->d_steps + L.first, L.count, p->d_Lsx, p->d_flags, p->epoch, p->d_info, st); break;
+            case 5: sf::launch_step(p->d_steps + L.first, L.count, p->lu ? 1 : 0, p->d_Lsx, p->d_flags, p->epoch, p->d_info, st); break;
             case 2:
             case 3:
             case 4: {

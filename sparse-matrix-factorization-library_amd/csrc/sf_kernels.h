@@ -58,11 +58,13 @@ struct TrsmTask {   // rows [row0, row0+nrows) of panel columns [diag, diag+b) <
 };
 
 struct StepTask {   // fused 64-column step on rows [row0, row0+nrows) of panel columns [diag, diag+b), updated by columns [J, diag)
-    int64_t panel;
+    int64_t panel;          // panel of the tile (and of its own rows' operand)
+    int64_t xpanel;         // panel of the other operand = the diagonal block's rows, and of the triangular block the rows are
+                            // solved against (Cholesky: == panel; LU: the U^T panel for L rows and vice versa)
     int32_t ld, J, diag, b;
-    int32_t row0, nrows;    // row0 == diag: the diagonal block (POTRF, publishes `flag`); else rows below it (wait for `flag`)
+    int32_t row0, nrows;    // row0 == diag: the diagonal block (POTRF / GETRF, publishes `flag`); else rows below it (wait for `flag`)
     int32_t flag;           // index of this (panel, step)'s flag
-    int32_t pad;
+    int32_t mode;           // bit 0: the triangular block has an implicit unit diagonal (LU: U12^T <- U12^T L11^{-T})
 };
 
 // skip_diag != 0: entries with row == column are not stored (LU: the L panel)
@@ -79,7 +81,8 @@ void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
 // tasks: the diagonal blocks first, then the 64-row tiles below them; at most GEMM_GRID tasks (all resident at once);
 // flags[task.flag] == epoch once that diagonal block is factored
-void launch_step(const StepTask* tasks, int ntasks, double* Lsx, int* flags, int epoch, int* info, hipStream_t st);
+// lu != 0: the diagonal tasks hold (L panel, U^T panel) and are factored without pivoting
+void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, hipStream_t st);
 // One-time (plan creation): relative maps of all scatter problems [first, first+count) -- the device form of the
 // reference's createRelativeMap (cuda_kernel.cu:42-60): RelMap[map_off + ci] = position of source row ci in the
 // target supernode's row list.

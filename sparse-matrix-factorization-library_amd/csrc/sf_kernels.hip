@@ -596,6 +596,7 @@ constexpr int ST_KC = 32;                // K chunk of the update's LDS-staged o
 constexpr int ST_XLD = ST_ROWS + 16;     // its LDS row stride
 constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 
+template <bool LU>
 __global__ void __launch_bounds__(256, 2)
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info) {
     // one LDS array: U[c][r] (updated tile) | Dt[k][j] = L(j,k), k < j (rows path); the X staging buffers of the
@@ -615,7 +616,9 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     const int b = t.b, nrows = t.nrows;
     const int nhp = (t.diag - t.J) / NB;             // K = 64 nhp = 2 nhp chunks of ST_KC = 32
     double* __restrict__ Ag = Lsx + t.panel + t.row0 + (int64_t)t.diag * ld;          // this tile: rows row0.., columns diag..
-    const double* __restrict__ Dg = Lsx + t.panel + t.diag + (int64_t)t.diag * ld;   // the diagonal block
+    // the diagonal block in the panel the OTHER operand comes from (Cholesky: the same panel; LU: L rows are updated with
+    // and solved against the U^T panel's block and vice versa)
+    const double* __restrict__ Dg = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
 
     // Update: wave w owns rows 16 w .. 16 w + 15 of the tile x all 64 columns (4 MFMA tiles).  Its own rows' fragments
     // (B operand) come straight from the panel, one chunk ahead in registers -- each element is loaded once; the
@@ -630,7 +633,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         const int nch = 2 * nhp;
         const int prow = 2 * (tid & 31), pk0 = tid >> 5;       // row pair, k = pk0 + 8 q
         // rows beyond b / nrows are clamped: their values only reach accumulator entries replaced by the padding below
-        const double* __restrict__ xp = Lsx + t.panel + t.diag + (int64_t)t.J * ld + ((prow < b) ? prow : 0);
+        const double* __restrict__ xp = Lsx + t.xpanel + t.diag + (int64_t)t.J * ld + ((prow < b) ? prow : 0);
         const double* __restrict__ yp = Lsx + t.panel + t.row0 + (int64_t)(t.J + fk) * ld + min(16 * wave + fr, nrows - 1);
         double2_t rx[4];
         double fy[2][8];
@@ -685,11 +688,53 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             for (int r = 0; r < 4; ++r) {
                 const int cj = 16 * q + fk + 4 * r;
                 double v = (is_diag && ci == cj) ? 1.0 : 0.0;
-                if (ci < nrows && cj < b && (!is_diag || cj <= ci)) v = Ag[ci + (int64_t)cj * ld] - acc[q][r];
+                if (LU && is_diag) {
+                    // the full block: D(ci,cj) lives in the L panel for cj < ci, in the U^T panel (transposed) otherwise
+                    if (ci < b && cj < b) v = ((cj < ci) ? Ag[ci + (int64_t)cj * ld] : Dg[cj + (int64_t)ci * ld]) - acc[q][r];
+                } else if (ci < nrows && cj < b && (!is_diag || cj <= ci)) {
+                    v = Ag[ci + (int64_t)cj * ld] - acc[q][r];
+                }
                 U[cj * ST_ULD + ci] = v;
             }
     }
 
+    if (LU && is_diag) {
+        __syncthreads();
+        if (wave != 0) return;
+        // no-pivot LU of the updated block (k_getrf_block's scheme): lane r holds row r, multipliers l(r,j) = a(r,j) / pivot
+        // with the reciprocal from v_rcp_f64 + two Newton steps (the IEEE divide sequence sits on the 64-step critical path)
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = U[c * ST_ULD + lane];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double piv = readlane_f64(a[j], j);
+            bad = bad || !(piv != 0.0);
+            double rp = __builtin_amdgcn_rcp(piv);
+            rp = rp * (2.0 - piv * rp);
+            rp = rp * (2.0 - piv * rp);
+            const double l = (lane > j) ? a[j] * rp : 0.0;
+            if (lane > j) a[j] = l;
+#pragma unroll
+            for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_f64(a[c], j);
+        }
+        if (bad && lane == 0) atomicExch(info, 1);
+        double* __restrict__ PUd = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if (lane < b && c < b) {
+                if (c < lane) Ag[lane + (int64_t)c * ld] = a[c]; else PUd[c + (int64_t)lane * ld] = a[c];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flags + t.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     if (is_diag) {
         __syncthreads();
         // POTRF of the updated block, blocked by 16 columns.  Panel part: wave 0, lane r holds row r of the 16 columns
@@ -774,7 +819,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         const int k = e / NB, j = e % NB;
         Dt[k][j] = (j < b && k < j) ? Dg[j + (int64_t)k * ld] : 0.0;
     }
-    if (tid < NB) Dinv[tid] = (tid < b) ? 1.0 / Dg[tid + (int64_t)tid * ld] : 1.0;
+    if (tid < NB) Dinv[tid] = (tid < b && !(t.mode & 1)) ? 1.0 / Dg[tid + (int64_t)tid * ld] : 1.0;      // mode bit 0: unit diagonal
     __syncthreads();
 
     // X <- X D^{-T}, blocked by 16 columns: wave 0 solves the 16 columns of block q by substitution (lane = row),
@@ -832,9 +877,10 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     }
 }
 
-void launch_step(const StepTask* tasks, int ntasks, double* Lsx, int* flags, int epoch, int* info, hipStream_t st) {
+void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, hipStream_t st) {
     if (ntasks <= 0) return;
-    hipLaunchKernelGGL(k_step, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info);
+    if (lu) hipLaunchKernelGGL(k_step<true>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info);
+    else hipLaunchKernelGGL(k_step<false>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info);
 }
 
 // relative map of every scatter problem: one workgroup per problem, lanes stride over its M source rows
