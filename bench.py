@@ -89,8 +89,10 @@ def main():
 
     lu = args.method == "lu"
     N = args.grid or (79 if lu else (1000 if args.workload == "stencil2d" else 128))
-    shard_one = world > 1 and args.mp.startswith("subtree") and not lu
-    if shard_one and args.scale == "weak" and args.workload == "lap3d":
+    shard_one = world > 1 and args.mp.startswith("subtree")
+    if lu and shard_one and args.mp != "subtree":
+        raise SystemExit("sharded LU supports --mp subtree (distributed top) only")
+    if shard_one and args.scale == "weak" and (lu or args.workload == "lap3d"):
         N = int(round(N * world ** (1.0 / 6.0)))      # F ~ g^6: the flops per GPU stay those of the base grid
     t0 = time.time()
 
@@ -113,7 +115,10 @@ def main():
     if shard_one:
         sharded = sf.ShardedCholesky(sym, rank, world, device=local_rank,
                                      mode="distributed" if args.mp == "subtree" else "replicated")
-        sharded.set_values(sym.Lx)
+        if lu:
+            sharded.set_values(sym.Lx, sym.Ux)
+        else:
+            sharded.set_values(sym.Lx)
         plan = sharded.engine.plan
     elif lu:
         plan = sf.LUPlan(sym, device=local_rank)
@@ -236,7 +241,7 @@ def main():
         import oracle
         Lsx = sharded.gather_factor()
         if rank == 0:
-            res, _ = oracle.chol_residual(sym, Lsx)
+            res, _ = (oracle.lu_residual if lu else oracle.chol_residual)(sym, Lsx)
             out["config"]["residual"] = res
         del Lsx
     elif args.check and rank == 0:

@@ -184,6 +184,13 @@ int sf_lu_plan_create(sf_lu_plan **plan, int device, sf_long n, sf_long nsuper,
                       const sf_long *Super, const sf_long *SuperMap,
                       const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                       const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui);
+/* multi-GPU: as sf_chol_plan_create_distributed; the phase / segment / pack / stream entry points of sf_chol_plan_*
+ * take an LU plan as they are (same handle type); each segment carries the L and the U^T blocks */
+int sf_lu_plan_create_distributed(sf_lu_plan **plan, int device, sf_long n, sf_long nsuper,
+                                  const sf_long *Super, const sf_long *SuperMap,
+                                  const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                                  const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
+                                  const int32_t *phase, int load_top, int rank, int nranks);
 int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *Ux /* NULL if U aliases L */);
 int sf_lu_plan_factorize(sf_lu_plan *plan, int sync);
 int sf_lu_plan_sync(sf_lu_plan *plan);

@@ -14,4 +14,4 @@ from .api import (  # noqa: F401
     REFERENCE_SLOT_1GPU, REFERENCE_SLOT_8GPU,
 )
 from . import gen  # noqa: F401
-from .sharded import ShardedCholesky  # noqa: F401
+from .sharded import ShardedCholesky, ShardedFactorization  # noqa: F401

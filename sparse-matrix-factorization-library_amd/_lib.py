@@ -116,6 +116,9 @@ lib.sf_chol_plan_set_stream.argtypes = [C.c_void_p, C.c_void_p]
 lib.sf_chol_plan_set_stream.restype = C.c_int
 lib.sf_lu_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9
 lib.sf_lu_plan_create.restype = C.c_int
+lib.sf_lu_plan_create_distributed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9 + \
+    [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int]
+lib.sf_lu_plan_create_distributed.restype = C.c_int
 lib.sf_lu_plan_set_values.argtypes = [C.c_void_p, c_double_p, c_double_p]
 lib.sf_lu_plan_set_values.restype = C.c_int
 lib.sf_lu_plan_factorize.argtypes = [C.c_void_p, C.c_int]

@@ -172,40 +172,8 @@ def phases_for_rank(owner, rank):
     return np.where(owner == rank, 0, np.where(owner < 0, 1, -1)).astype(np.int32)
 
 
-class CholPlan:
-    """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present.
-    phase/load_top: multi-GPU sharding (sf_chol_plan_create_sharded); default = the whole matrix on one device.
-    rank/nranks (with phase): distributed top (sf_chol_plan_create_distributed), run with factorize_phase(0) and then
-    factorize_segment(k) after summing segment_regions(k) over the ranks."""
-
-    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1):
-        h = C.c_void_p()
-        self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
-        if phase is None:
-            check(lib.sf_chol_plan_create(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep]),
-                  "sf_chol_plan_create")
-        elif nranks <= 1:
-            phase = np.ascontiguousarray(phase, dtype=np.int32)
-            check(lib.sf_chol_plan_create_sharded(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
-                                                  phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0),
-                  "sf_chol_plan_create_sharded")
-        else:
-            phase = np.ascontiguousarray(phase, dtype=np.int32)
-            check(lib.sf_chol_plan_create_distributed(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
-                                                      phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0,
-                                                      int(rank), int(nranks)),
-                  "sf_chol_plan_create_distributed")
-        self.device = device
-        self._h = h
-        self.xsize = sym.xsize
-        self.n = sym.n
-
-    def set_values(self, Lx):
-        Lx = _f64(Lx)
-        check(lib.sf_chol_plan_set_values(self._h, _dp(Lx)), "sf_chol_plan_set_values")
-
-    def factorize(self, sync=True):
-        check(lib.sf_chol_plan_factorize(self._h, 1 if sync else 0), "sf_chol_plan_factorize")
+class _ShardedPlanMixin:
+    """multi-GPU entry points shared by CholPlan and LUPlan (one handle type in the C ABI)"""
 
     def factorize_phase(self, which, sync=True):
         check(lib.sf_chol_plan_factorize_phase(self._h, which, 1 if sync else 0), "sf_chol_plan_factorize_phase")
@@ -243,6 +211,46 @@ class CholPlan:
         check(lib.sf_chol_plan_top_region(self._h, C.byref(ptr), C.byref(cnt)), "sf_chol_plan_top_region")
         return ptr.value or 0, cnt.value
 
+    @property
+    def factor_device_ptr(self):
+        return lib.sf_chol_plan_factor_device_ptr(self._h)
+
+
+class CholPlan(_ShardedPlanMixin):
+    """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present.
+    phase/load_top: multi-GPU sharding (sf_chol_plan_create_sharded); default = the whole matrix on one device.
+    rank/nranks (with phase): distributed top (sf_chol_plan_create_distributed), run with factorize_phase(0) and then
+    factorize_segment(k) after summing segment_regions(k) over the ranks."""
+
+    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1):
+        h = C.c_void_p()
+        self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
+        if phase is None:
+            check(lib.sf_chol_plan_create(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep]),
+                  "sf_chol_plan_create")
+        elif nranks <= 1:
+            phase = np.ascontiguousarray(phase, dtype=np.int32)
+            check(lib.sf_chol_plan_create_sharded(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
+                                                  phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0),
+                  "sf_chol_plan_create_sharded")
+        else:
+            phase = np.ascontiguousarray(phase, dtype=np.int32)
+            check(lib.sf_chol_plan_create_distributed(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
+                                                      phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0,
+                                                      int(rank), int(nranks)),
+                  "sf_chol_plan_create_distributed")
+        self.device = device
+        self._h = h
+        self.xsize = sym.xsize
+        self.n = sym.n
+
+    def set_values(self, Lx):
+        Lx = _f64(Lx)
+        check(lib.sf_chol_plan_set_values(self._h, _dp(Lx)), "sf_chol_plan_set_values")
+
+    def factorize(self, sync=True):
+        check(lib.sf_chol_plan_factorize(self._h, 1 if sync else 0), "sf_chol_plan_factorize")
+
     def sync(self):
         check(lib.sf_chol_plan_sync(self._h), "sf_chol_plan_sync")
 
@@ -265,10 +273,6 @@ class CholPlan:
     def set_profiling(self, on=True):
         check(lib.sf_chol_plan_set_profiling(self._h, 1 if on else 0), "sf_chol_plan_set_profiling")
 
-    @property
-    def factor_device_ptr(self):
-        return lib.sf_chol_plan_factor_device_ptr(self._h)
-
     def close(self):
         if getattr(self, "_h", None):
             lib.sf_chol_plan_destroy(self._h)
@@ -278,10 +282,11 @@ class CholPlan:
         self.close()
 
 
-class LUPlan:
-    """Device-resident supernodal no-pivot LU (flat ABI, sf_lu_plan_*).  `sym` comes from analyze(..., method='lu')."""
+class LUPlan(_ShardedPlanMixin):
+    """Device-resident supernodal no-pivot LU (flat ABI, sf_lu_plan_*).  `sym` comes from analyze(..., method='lu').
+    phase/load_top/rank/nranks: distributed multi-GPU plan (sf_lu_plan_create_distributed), as CholPlan."""
 
-    def __init__(self, sym, device=0):
+    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1):
         if not sym.lu:
             raise ValueError("LUPlan needs an LU symbolic analysis (method='lu')")
         h = C.c_void_p()
@@ -290,7 +295,14 @@ class LUPlan:
         if not self._alias:
             self._keep += [sym.Up, sym.Ui]
         args = [_lp(a) for a in self._keep] + ([None, None] if self._alias else [])
-        check(lib.sf_lu_plan_create(C.byref(h), device, sym.n, sym.nsuper, *args), "sf_lu_plan_create")
+        if phase is None:
+            check(lib.sf_lu_plan_create(C.byref(h), device, sym.n, sym.nsuper, *args), "sf_lu_plan_create")
+        else:
+            phase = np.ascontiguousarray(phase, dtype=np.int32)
+            check(lib.sf_lu_plan_create_distributed(C.byref(h), device, sym.n, sym.nsuper, *args,
+                                                    phase.ctypes.data_as(C.POINTER(C.c_int32)), 1 if load_top else 0,
+                                                    int(rank), int(nranks)), "sf_lu_plan_create_distributed")
+        self.device = device
         self._h = h
         self.xsize = sym.xsize
         self.n = sym.n
@@ -309,8 +321,10 @@ class LUPlan:
     def sync(self):
         check(lib.sf_lu_plan_sync(self._h), "sf_lu_plan_sync")
 
-    def get_factor(self):
-        out = np.empty(max(self.xsize, 1), dtype=np.float64)
+    def get_factor(self, out=None):
+        """D2H in the reference's packed layout; a sharded plan returns zeros for the panels of other ranks"""
+        if out is None:
+            out = np.empty(max(self.xsize, 1), dtype=np.float64)
         check(lib.sf_lu_plan_get_factor(self._h, _dp(out)), "sf_lu_plan_get_factor")
         return out[:self.xsize]
 

@@ -214,7 +214,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                        const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1) {
     if (!out) return SF_ERR_ARG;
     *out = nullptr;
-    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (lu || !phase_in))) return SF_ERR_ARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !phase_in)) return SF_ERR_ARG;
     if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
     if (n >= (sf_long)0x7fffffff) return SF_ERR_ARG;   // device row indices are 32-bit
     int ndev = 0;
@@ -386,13 +386,16 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
                     if (J >= nscol) continue;
                     const int64_t w = std::min<int64_t>(sf::OUTER_NB, nscol - J);
-                    sg.off.push_back(XP[s] + (int64_t)J * nsrow);
-                    sg.cnt.push_back(w * nsrow);
-                    sg.src.push_back(XP[s] + (int64_t)J * nsrow + J);
-                    sg.rows.push_back(nsrow - J);
-                    sg.cols.push_back(w);
-                    sg.ld.push_back(nsrow);
-                    sg.packed += (nsrow - J) * w;
+                    for (int side = 0; side < (lu ? 2 : 1); ++side) {         // LU: the L panel and the U^T panel
+                        const int64_t base = XP[s] + (side ? ushift : 0);
+                        sg.off.push_back(base + (int64_t)J * nsrow);
+                        sg.cnt.push_back(w * nsrow);
+                        sg.src.push_back(base + (int64_t)J * nsrow + J);
+                        sg.rows.push_back(nsrow - J);
+                        sg.cols.push_back(w);
+                        sg.ld.push_back(nsrow);
+                        sg.packed += (nsrow - J) * w;
+                    }
                 }
                 p->segments.push_back(std::move(sg));
             }
@@ -722,6 +725,14 @@ int sf_chol_plan_set_values(sf_chol_plan* p, const sf_float* Lx) {
     return SF_OK;
 }
 
+int sf_lu_plan_create_distributed(sf_lu_plan** out, int device, sf_long n, sf_long nsuper,
+                                  const sf_long* Super, const sf_long* SuperMap,
+                                  const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                                  const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
+                                  const int32_t* phase, int load_top, int rank, int nranks) {
+    return plan_create(out, device, true, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, phase, load_top, rank, nranks);
+}
+
 int sf_lu_plan_set_values(sf_lu_plan* p, const sf_float* Lx, const sf_float* Ux) {
     if (!p || !p->lu || (!Lx && p->nnz > 0) || (!p->u_alias && !Ux && p->unz > 0)) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
@@ -945,7 +956,7 @@ int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
         }
         return SF_OK;
     }
-    if (p->partial) return SF_ERR_ARG;   // sharded LU download: not built
+    // (sharded LU: panels not stored on this rank come back as zeros, k_pack_lu skips them)
     if (!p->d_pack) {
         HIP_TRY(hipMalloc((void**)&p->d_pack, p->xsize * sizeof(double)));
         p->bytes_device += p->xsize * sizeof(double);

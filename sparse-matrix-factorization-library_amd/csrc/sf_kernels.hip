@@ -186,6 +186,7 @@ k_pack_lu(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsip, c
             if (RefXp[mid] <= e) lo = mid; else hi = mid;
         }
         const int s = lo;
+        if (Xp[s] < 0) { out[e] = 0.0; continue; }      // sharded plan: the panel lives on another rank
         const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
         const int64_t lda = 2 * nsrow - nscol;
         const int64_t off = e - RefXp[s];

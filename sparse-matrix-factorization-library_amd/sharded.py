@@ -1,4 +1,4 @@
-"""One Cholesky factorization sharded over the ranks of a torch.distributed group by elimination-tree subtrees
+"""One factorization (Cholesky, or no-pivot LU in the distributed mode) sharded over the ranks of a torch.distributed group by elimination-tree subtrees
 (SURVEY 8e).  One process per GPU; the data-path exchange is sum all-reduces (RCCL over xGMI on GPUs, gloo in the
 CPU tests) of top-panel regions.  Two ways of handling the top supernodes (those above the subtrees):
 
@@ -21,7 +21,7 @@ methods (tests use a numpy engine so that the orchestration runs under gloo with
 """
 import numpy as np
 
-from .api import CholPlan, subtree_partition, phases_for_rank
+from .api import CholPlan, LUPlan, subtree_partition, phases_for_rank
 
 #: cost of a top flop relative to a subtree flop in the distributed mode: the split share plus the replicated
 #: 64-column chain and the all-reduce (about a quarter of the top's single-GPU time at 128^3)
@@ -39,8 +39,15 @@ class _DevArray:
 class HipEngine:
     def __init__(self, sym, phase, load_top, device, rank=0, world=1, distributed=False):
         self.distributed = bool(distributed and world > 1)
-        self.plan = CholPlan(sym, device=device, phase=phase, load_top=load_top,
-                             rank=rank if self.distributed else 0, nranks=world if self.distributed else 1)
+        self.lu = bool(getattr(sym, "lu", False))
+        if self.lu and world > 1 and not self.distributed:
+            raise ValueError("sharded LU needs mode='distributed'")
+        cls = LUPlan if self.lu else CholPlan
+        if self.lu and world == 1:
+            self.plan = LUPlan(sym, device=device)
+        else:
+            self.plan = cls(sym, device=device, phase=phase, load_top=load_top,
+                            rank=rank if self.distributed else 0, nranks=world if self.distributed else 1)
         self.device = device
         self._top = None
         self._seg = {}
@@ -49,8 +56,11 @@ class HipEngine:
             import torch
             self.plan.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
-    def set_values(self, Lx):
-        self.plan.set_values(Lx)
+    def set_values(self, Lx, Ux=None):
+        if self.lu:
+            self.plan.set_values(Lx, Ux)
+        else:
+            self.plan.set_values(Lx)
 
     def factorize_phase(self, which):
         # replicated mode: synchronous on the plan's own stream, the collective that follows runs on torch's stream
@@ -95,7 +105,7 @@ class HipEngine:
         self.plan.close()
 
 
-class ShardedCholesky:
+class ShardedFactorization:
     def __init__(self, sym, rank, world, device=0, engine_factory=None, group=None, mode="distributed"):
         if mode not in ("distributed", "replicated"):
             raise ValueError("mode must be 'distributed' or 'replicated'")
@@ -119,8 +129,11 @@ class ShardedCholesky:
                 "segments": self.engine.num_segments() if self.mode == "distributed" else 0,
                 "model_speedup_bound": 1.0 / cost if cost > 0 else float(self.world)}
 
-    def set_values(self, Lx):
-        self.engine.set_values(Lx)
+    def set_values(self, Lx, Ux=None):
+        if Ux is None:
+            self.engine.set_values(Lx)
+        else:
+            self.engine.set_values(Lx, Ux)
 
     def factorize(self):
         import torch.distributed as dist
@@ -166,3 +179,7 @@ class ShardedCholesky:
 
     def close(self):
         self.engine.close()
+
+
+#: the Cholesky name the rest of the package and the tests use; LU goes through the same class (sym.lu selects the plan)
+ShardedCholesky = ShardedFactorization
