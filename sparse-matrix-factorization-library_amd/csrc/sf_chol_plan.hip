@@ -332,6 +332,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     };
 
     int32_t n_flags = 0;
+    // steps of up to this many workgroups run as ONE k_step launch (measured at 128^3: 512 -> 626 ms, 2048 -> 619, 4096 -> 618,
+    // all steps -> 622); beyond it the three-launch form (stream-K GEMM, 256-row TRSM workgroups) has the better throughput
+    const int64_t fuse_max = 4 * sf::GEMM_GRID;
     for (int ph = 0; ph < 2; ++ph) {
     if (ph == 1) p->launch_split = p->launches.size();
     std::vector<std::vector<sf_long>> by_level(nlevels);
@@ -412,10 +415,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
                     if (diag < nscol) step_wgs += 1 + (lu ? 2 : 1) * ((nsrow - std::min<int64_t>(nscol, diag + sf::NB) + sf::ST_ROWS - 1) / sf::ST_ROWS);
                 }
-                if (step_wgs <= sf::GEMM_GRID) {
-                    // latency-bound step (all its workgroups resident at once): the (update, POTRF / GETRF, TRSM) triple
-                    // is ONE launch of k_step.  Steps with more tiles are throughput-bound and keep the three
-                    // launches (stream-K GEMM over all tiles, 256-row TRSM workgroups).
+                if (step_wgs <= fuse_max) {
+                    // latency-bound step: the (update, POTRF / GETRF, TRSM) triple is ONE launch of k_step.  Steps with
+                    // more tiles are throughput-bound and keep the three launches (stream-K GEMM over all tiles,
+                    // 256-row TRSM workgroups).
                     const int64_t d0 = (int64_t)steps.size();
                     std::vector<int32_t> flag_of;
                     for (sf_long s : Sl) {
@@ -751,7 +754,8 @@ int sf_chol_plan_sync(sf_chol_plan* p) {
     HIP_TRY(hipMemcpy(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
     float ms = 0;
     if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_ms = ms;
-    p->last_status = info ? SF_ERR_NOT_POSDEF : SF_OK;
+    // 1: non-positive / zero pivot; 2: a fused step's flag wait timed out (internal error, never seen)
+    p->last_status = (info & 2) ? SF_ERR_HIP : (info ? SF_ERR_NOT_POSDEF : SF_OK);
     return p->last_status;
 }
 

@@ -114,7 +114,7 @@ k_potrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) a[c] -= lj * readlane_f64(lj, c);
     }
-    if (bad && lane == 0) atomicExch(info, 1);
+    if (bad && lane == 0) atomicOr(info, 1);
 #pragma unroll
     for (int c = 0; c < NB; ++c)
         if (lane < b && c <= lane) A[lane + c * ld] = a[c];
@@ -158,7 +158,7 @@ k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_f64(a[c], j);
     }
-    if (bad && lane == 0) atomicExch(info, 1);
+    if (bad && lane == 0) atomicOr(info, 1);
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
         if (lane < b && c < b) {
@@ -576,17 +576,18 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fused 64-column step of the in-panel factorization (Cholesky, latency-bound steps: at most GEMM_GRID
-// workgroups, so that all of them are resident at once).  ONE launch does what used to be three
-// (left-looking update K = 64 t, POTRF of the diagonal block, TRSM of the rows below):
-//   diagonal workgroup (one per panel):   D <- D - Y_D Y_D^T (MFMA) ; D <- chol(D)  (registers of wave 0) ; publish
+// Fused 64-column step of the in-panel factorization (latency-bound steps: up to a few rounds of workgroups).
+// ONE launch does what used to be three (left-looking update K = 64 t, POTRF / GETRF of the diagonal block, TRSM of
+// the rows below):
+//   diagonal workgroup (one per panel):   D <- D - Y_D Y_D^T (MFMA) ; D <- chol(D)  (blocked, wave 0 + MFMA) ; publish
 //   row workgroups (one per 64 rows):     R <- R - Y_R Y_D^T (MFMA) ; wait for D ; R <- R D^{-T} (blocked, MFMA)
 // The row workgroups' update -- most of the step's work -- runs WHILE the diagonal block is being factored; they
-// pick the factored block up through a per-(panel, step) flag (release store after __threadfence by the diagonal
-// workgroup, acquire load by the waiting one, device scope; the flag value is the factorization's epoch, so flags
-// are never reset).  Diagonal workgroups have the lowest block indices, i.e. they are dispatched first, and the
-// launch never exceeds the number of resident workgroup slots: a waiting workgroup cannot keep the one it waits
-// for off the chip.  The wait is bounded all the same (info = 2 instead of a hang).
+// pick the factored block up through a per-(panel, step) flag (release fence + relaxed store by the diagonal
+// workgroup, relaxed polls + one acquire fence by the waiting one, device scope; the flag value is the
+// factorization's epoch, so flags are never reset).  Liveness: diagonal workgroups never wait and have the lowest
+// block indices, so on every XCD (each dispatches its share of the grid in index order) they are placed before any
+// row workgroup of that XCD -- a waiting workgroup cannot keep the one it waits for off the chip, whatever the
+// grid size.  The wait is bounded all the same (info |= 2 -> SF_ERR_HIP instead of a hang).
 // Every element of the block column is read and written once.  4 waves (2 x 2), each a 32 x 32 sub-tile = 2 x 2
 // v_mfma_f64_16x16x4_f64 tiles; K is short (<= 448), so the MFMA fragments are loaded straight from the panel
 // (16 consecutive rows x 4 k per load), 32 k ahead in registers, no LDS staging and no barriers in the K loop.
@@ -720,7 +721,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 #pragma unroll
             for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_f64(a[c], j);
         }
-        if (bad && lane == 0) atomicExch(info, 1);
+        if (bad && lane == 0) atomicOr(info, 1);
         double* __restrict__ PUd = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
@@ -791,7 +792,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             __syncthreads();
         }
         if (wave != 0) return;
-        if (bad && lane == 0) atomicExch(info, 1);
+        if (bad && lane == 0) atomicOr(info, 1);
         // publish: every lane's stores of the block have left the wave, then ONE device-scope release by lane 0, then
         // the flag (the explicit waits keep the order whatever the compiler does with the fence's own wait)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -810,7 +811,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         // waiting workgroups that slows the whole chip down); ONE acquire fence once the flag is seen
         while (__hip_atomic_load(flags + t.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > ST_SPIN_LIMIT) { atomicExch(info, 2); break; }
+            if (++spins > ST_SPIN_LIMIT) { atomicOr(info, 2); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
