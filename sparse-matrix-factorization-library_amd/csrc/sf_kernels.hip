@@ -275,7 +275,12 @@ k_solve_fwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__
     const int64_t ld = t.ld;
     double a[NB];       // unit: the diagonal is implied (LU: the L panel stores only the strictly lower part)
 #pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = (lane < b && c + unit <= lane) ? D[lane + c * ld] : ((c == lane) ? 1.0 : 0.0);
+    for (int c = 0; c < NB; ++c) {
+        // unconditional load from a clamped address, then select: a load under a per-element condition becomes a branch
+        // plus its own s_waitcnt, i.e. 64 dependent round trips (26 of this kernel's 31 us)
+        const double v = D[min(lane, b - 1) + (int64_t)min(c, b - 1) * ld];
+        a[c] = (lane < b && c + unit <= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+    }
     double* xb = x + t.first_col + t.diag;
     double v = (lane < b) ? xb[lane] : 0.0;
 #pragma unroll
@@ -341,8 +346,13 @@ k_solve_bwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__
     const SolveTask t = tasks[blockIdx.x];
     const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
     const int lane = threadIdx.x, b = t.b;
-    for (int c = 0; c < b; ++c)
-        if (lane < b) Dl[c][lane] = (lane >= c) ? D[lane + (int64_t)c * t.ld] : 0.0;     // Dl[c][r] = D(r,c), coalesced along r
+    {   // Dl[c][r] = D(r,c), coalesced along r; all 64 loads in flight (clamped addresses), then the LDS stores
+        double col[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) col[c] = D[min(lane, b - 1) + (int64_t)min(c, b - 1) * t.ld];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) Dl[c][lane] = (lane < b && c < b && lane >= c) ? col[c] : 0.0;
+    }
     __syncthreads();
     double bcol[NB];    // bcol[c] = D(c, lane): column `lane` of D, rows c >= lane
 #pragma unroll
@@ -443,7 +453,6 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         const int nkt = (int)(kt_prefix[ti + 1] - tbase);
         const int kt0 = (int)(u - tbase);
         const int kt1 = min(nkt, kt0 + (int)(u_end - u));
-        const bool partial = (kt0 > 0) || (kt1 < nkt);
         u += (uint32_t)(kt1 - kt0);
         ++ti;
 
@@ -563,7 +572,10 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                                 unsafeAtomicAdd(Cg + rowmap[lci] + (int64_t)colmap[lcj] * ldc, -v);
                             } else {
                                 double* dst = Cg + ci + (int64_t)cj * ldc;
-                                if (partial || (pb.strict & 2)) unsafeAtomicAdd(dst, -v); else *dst -= v;   // strict bit 1: forced by tools/gemm_bench only
+                                // always the atomic form: a plain read-modify-write makes every one of the lane's 32 loads a
+                                // dependent round trip (wait, subtract, store); the atomic needs no return value (measured:
+                                // 49.6 vs 46.3 TFLOP/s at K = 256, profiles/r01_g_gemm_microbench_8wave.txt)
+                                unsafeAtomicAdd(dst, -v);
                             }
                         }
                     }
@@ -689,12 +701,17 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cj = 16 * q + fk + 4 * r;
+                // loads are unconditional (clamped addresses) and selected afterwards: a load under a per-element
+                // condition costs a branch and its own wait, i.e. 16 dependent round trips per lane
+                const int cic = min(ci, nrows - 1), cjc = min(cj, b - 1);
                 double v = (is_diag && ci == cj) ? 1.0 : 0.0;
                 if (LU && is_diag) {
                     // the full block: D(ci,cj) lives in the L panel for cj < ci, in the U^T panel (transposed) otherwise
-                    if (ci < b && cj < b) v = ((cj < ci) ? Ag[ci + (int64_t)cj * ld] : Dg[cj + (int64_t)ci * ld]) - acc[q][r];
-                } else if (ci < nrows && cj < b && (!is_diag || cj <= ci)) {
-                    v = Ag[ci + (int64_t)cj * ld] - acc[q][r];
+                    const double dl = Ag[cic + (int64_t)cjc * ld], du = Dg[cjc + (int64_t)cic * ld];
+                    if (ci < b && cj < b) v = ((cj < ci) ? dl : du) - acc[q][r];
+                } else {
+                    const double av = Ag[cic + (int64_t)cjc * ld];
+                    if (ci < nrows && cj < b && (!is_diag || cj <= ci)) v = av - acc[q][r];
                 }
                 U[cj * ST_ULD + ci] = v;
             }
@@ -817,11 +834,23 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int k = e / NB, j = e % NB;
-        Dt[k][j] = (j < b && k < j) ? Dg[j + (int64_t)k * ld] : 0.0;
+    {
+        double dv[NB * NB / 256];
+#pragma unroll
+        for (int i = 0; i < NB * NB / 256; ++i) {       // all 16 loads in flight (clamped addresses), then select + store
+            const int e = tid + 256 * i, k = e / NB, j = e % NB;
+            dv[i] = Dg[min(j, b - 1) + (int64_t)min(k, b - 1) * ld];
+        }
+#pragma unroll
+        for (int i = 0; i < NB * NB / 256; ++i) {
+            const int e = tid + 256 * i, k = e / NB, j = e % NB;
+            Dt[k][j] = (j < b && k < j) ? dv[i] : 0.0;
+        }
     }
-    if (tid < NB) Dinv[tid] = (tid < b && !(t.mode & 1)) ? 1.0 / Dg[tid + (int64_t)tid * ld] : 1.0;      // mode bit 0: unit diagonal
+    if (tid < NB) {
+        const double dd = Dg[min(tid, b - 1) + (int64_t)min(tid, b - 1) * ld];
+        Dinv[tid] = (tid < b && !(t.mode & 1)) ? 1.0 / dd : 1.0;      // mode bit 0: unit diagonal
+    }
     __syncthreads();
 
     // X <- X D^{-T}, blocked by 16 columns: wave 0 solves the 16 columns of block q by substitution (lane = row),
