@@ -238,11 +238,17 @@ k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx) {
     for (int jb = 0; jb < b; jb += 8) {
         double acc[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = (jb + u < b) ? X[(jb + u) * ld] : 0.0;
-        for (int k = 0; k < jb; ++k) {
-            const double xk = X[k * ld];
+        for (int u = 0; u < 8; ++u) acc[u] = X[min(jb + u, b - 1) * ld];      // unconditional, clamped: 8 loads in flight
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] -= xk * Dt[k][jb + u];
+        for (int u = 0; u < 8; ++u) acc[u] = (jb + u < b) ? acc[u] : 0.0;
+        for (int k0 = 0; k0 < jb; k0 += 8) {       // jb is a multiple of 8: 8 independent re-reads in flight per round trip
+            double xk[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) xk[v] = X[(k0 + v) * ld];
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] -= xk[v] * Dt[k0 + v][jb + u];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
