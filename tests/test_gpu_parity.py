@@ -276,6 +276,21 @@ def test_distributed_top_emulated_ranks_on_one_gpu(oracle, world):
         e.close()
 
 
+def test_rccl_world1_collectives_on_plan_memory():
+    """the real RCCL backend on the plan's memory and stream (one-rank group; see tests/_nccl_world1_worker.py)"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "_nccl_world1_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, p.stdout[-3000:]
+
+
 @pytest.mark.parametrize("case", small_cases(), ids=lambda c: c[0])
 def test_device_solve_matches_oracle(oracle, case):
     """sf_chol_plan_solve (level-scheduled, factor resident) vs the reference's host loops (oracle restatement)"""
