@@ -132,6 +132,7 @@ struct sf_chol_plan {
     TrsmTask* d_trsm = nullptr;
     StepTask* d_steps = nullptr;
     int* d_flags = nullptr;     // k_step: one flag per (panel, fused step); == epoch once its diagonal block is factored
+    double* d_tinv = nullptr;   // k_step: inverses of the 16 x 16 diagonal sub-blocks, per diagonal task of the running launch
     int epoch = 0;
     GemmProb* d_probs = nullptr;
     GemmTask* d_gtasks = nullptr;
@@ -186,7 +187,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
-                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_probs, p->d_gtasks, p->d_ktprefix,
+                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_ktprefix,
                     p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x, p->d_relmap, p->d_scratch};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -332,9 +333,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     };
 
     int32_t n_flags = 0;
-    // steps of up to this many workgroups run as ONE k_step launch (measured at 128^3: 512 -> 626 ms, 2048 -> 619, 4096 -> 618,
-    // all steps -> 622); beyond it the three-launch form (stream-K GEMM, 256-row TRSM workgroups) has the better throughput
-    const int64_t fuse_max = 4 * sf::GEMM_GRID;
+    int64_t max_diag_tasks = 0;     // k_step launches: scratch for the 16 x 16 inverses, 1024 doubles per diagonal task
+    // steps of up to this many workgroups run as ONE k_step launch; beyond it (swarms of tiny panels at the bottom levels)
+    // the three-launch form -- stream-K GEMM, one-wave POTRF, 256-row TRSM workgroups -- has the better throughput.
+    // Measured: 128^3 608 ms at 2048, 603 at 8192, 600 at 16384, 602 unlimited; 2-D 1000^2 (config 3) 12.0 ms up to 16384,
+    // 12.3 at 32768, 13.3 unlimited
+    // (LU: k_step<true> still solves by substitution, 2 workgroups per CU: 93 ms at 2048 vs 95 at 16384 on config 5)
+    const int64_t fuse_max = (lu ? 4 : 32) * sf::GEMM_GRID;
     for (int ph = 0; ph < 2; ++ph) {
     if (ph == 1) p->launch_split = p->launches.size();
     std::vector<std::vector<sf_long>> by_level(nlevels);
@@ -420,32 +425,35 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     // more tiles are throughput-bound and keep the three launches (stream-K GEMM over all tiles,
                     // 256-row TRSM workgroups).
                     const int64_t d0 = (int64_t)steps.size();
-                    std::vector<int32_t> flag_of;
+                    std::vector<int32_t> flag_of, slot_of;
                     for (sf_long s : Sl) {
                         const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
-                        if (diag >= nscol) { flag_of.push_back(-1); continue; }
+                        if (diag >= nscol) { flag_of.push_back(-1); slot_of.push_back(-1); continue; }
                         const int b = std::min(sf::NB, nscol - diag);
                         flag_of.push_back(n_flags);
-                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, J, diag, b, diag, b, n_flags++, 0});
+                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, J, diag, b, diag, b, n_flags++, 0, (int32_t)(steps.size() - d0), 0});
+                        slot_of.push_back((int32_t)(steps.size() - 1 - d0));
                         if (ti > 0) p->flops_panel_gemm += (lu ? 2.0 : 1.0) * ((double)b * (b + 1) * (diag - J) + 2.0 * (nsrow - diag - b) * (double)b * (diag - J));
                     }
                     size_t si = 0;
                     for (sf_long s : Sl) {
                         const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
-                        const int32_t fl = flag_of[si++];
+                        const int32_t fl = flag_of[si], sl = slot_of[si];
+                        ++si;
                         if (fl < 0) continue;
                         const int b = std::min(sf::NB, nscol - diag);
                         for (int r = diag + b; r < nsrow; r += sf::ST_ROWS) {
                             const int nr = std::min(sf::ST_ROWS, nsrow - r);
                             if (!lu) {
-                                steps.push_back(StepTask{XP[s], XP[s], nsrow, J, diag, b, r, nr, fl, 0});
+                                steps.push_back(StepTask{XP[s], XP[s], nsrow, J, diag, b, r, nr, fl, 0, sl, 0});
                             } else {
-                                steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, diag, b, r, nr, fl, 0});     // L21 <- (L21 - ..) U11^{-1}
-                                steps.push_back(StepTask{XP[s] + ushift, XP[s], nsrow, J, diag, b, r, nr, fl, 1});     // U12^T <- (U12^T - ..) L11^{-T}
+                                steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, diag, b, r, nr, fl, 0, sl, 0});     // L21 <- (L21 - ..) U11^{-1}
+                                steps.push_back(StepTask{XP[s] + ushift, XP[s], nsrow, J, diag, b, r, nr, fl, 1, sl, 0});     // U12^T <- (U12^T - ..) L11^{-T}
                             }
                         }
                     }
                     if ((int64_t)steps.size() > d0) p->launches.push_back(Launch{5, d0, (int)(steps.size() - d0)});
+                    max_diag_tasks = std::max<int64_t>(max_diag_tasks, (int64_t)slot_of.size());
                     continue;
                 }
                 const int64_t p0 = (int64_t)potrf.size(), t0 = (int64_t)trsm.size(), g0 = (int64_t)gtasks.size();
@@ -631,6 +639,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         {
             std::vector<int> zeros(std::max<int32_t>(n_flags, 1), 0);
             if ((rc = upload(&p->d_flags, zeros, &p->bytes_device))) break;
+            const size_t tb = (size_t)std::max<int64_t>(max_diag_tasks, 1) * 1024 * sizeof(double);
+            if (hipMalloc((void**)&p->d_tinv, tb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += tb;
         }
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
@@ -805,7 +816,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 else sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st);
                 break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
-            case 5: sf::launch_step(p->d_steps + L.first, L.count, p->lu ? 1 : 0, p->d_Lsx, p->d_flags, p->epoch, p->d_info, st); break;
+            case 5: sf::launch_step(p->d_steps + L.first, L.count, p->lu ? 1 : 0, p->d_Lsx, p->d_flags, p->epoch, p->d_info, p->d_tinv, st); break;
             case 2:
             case 3:
             case 4: {

@@ -617,16 +617,21 @@ constexpr int ST_XLD = ST_ROWS + 16;     // its LDS row stride
 constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 
 template <bool LU>
-__global__ void __launch_bounds__(256, 2)
-k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info) {
-    // one LDS array: U[c][r] (updated tile) | Dt[k][j] = L(j,k), k < j (rows path); the X staging buffers of the
-    // update alias both (they are dead before U / Dt are written)
-    __shared__ __attribute__((aligned(16))) double smem[NB * ST_ULD + NB * NB];
+__global__ void __launch_bounds__(256, LU ? 2 : 3)
+k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info,
+       double* __restrict__ tinv) {
+    // ONE LDS array, re-used by the phases of a task:
+    //   update:            X staging buffers Xs[2][32][80]
+    //   diagonal task:     U[c][r], the updated block (POTRF / GETRF works on it)
+    //   row task, Cholesky: Dt[k][j] = L(j,k) | Tl[4][16][16], the inverses of the four 16 x 16 diagonal sub-blocks
+    //   row task, LU:      U[c][r] | Dt[k][j]   (substitution solve)
+    constexpr int SMEM = LU ? (NB * ST_ULD + NB * NB) : (2 * ST_KC * ST_XLD);
+    __shared__ __attribute__((aligned(16))) double smem[SMEM];
     __shared__ double Dinv[NB];
     static_assert(NB == ST_ROWS && NB == 64, "one wavefront per 64 x 64 tile");
-    static_assert(2 * ST_KC * ST_XLD <= NB * ST_ULD + NB * NB, "X staging buffers must fit");
+    static_assert(2 * ST_KC * ST_XLD <= SMEM && NB * ST_ULD <= SMEM && NB * NB + 4 * 256 <= SMEM, "phases must fit the LDS array");
     double* __restrict__ U = smem;
-    double (*Dt)[NB] = reinterpret_cast<double (*)[NB]>(smem + NB * ST_ULD);
+    double (*Dt)[NB] = reinterpret_cast<double (*)[NB]>(LU ? smem + NB * ST_ULD : smem);
 
     const StepTask t = tasks[blockIdx.x];
     const bool is_diag = t.row0 == t.diag;
@@ -698,9 +703,23 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         }
     }
 
+    // Cholesky row task: the updated tile stays in the MFMA accumulator layout (wave w: rows 16 w + fr, column tile q:
+    // columns 16 q + fk + 4 r), which is also the B-operand layout of the next MFMA -- the solve below runs on registers
+    double4_t rt[4];
+    if (!LU && !is_diag) {
+        const int ci = 16 * wave + fr, cic = min(ci, nrows - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cj = 16 * q + fk + 4 * r;
+                const double av = Ag[cic + (int64_t)min(cj, b - 1) * ld];          // unconditional, clamped (see below)
+                rt[q][r] = (ci < nrows && cj < b) ? av - acc[q][r] : 0.0;
+            }
+    }
     // accumulators -> U[cj][ci] = A(ci, cj) - update (padded with the identity / zeros); the staging buffers are dead
     // (the chunk loop ends with a barrier)
-    {
+    if (LU || is_diag) {
         const int ci = 16 * wave + fr;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -814,12 +833,37 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             }
             __syncthreads();
         }
-        if (wave != 0) return;
-        if (bad && lane == 0) atomicOr(info, 1);
-        // publish: every lane's stores of the block have left the wave, then ONE device-scope release by lane 0, then
+        if (bad && wave == 0 && lane == 0) atomicOr(info, 1);
+        // Inverses of the four 16 x 16 diagonal sub-blocks of L (what MAGMA-style TRSMs use): wave w inverts block w by
+        // forward substitution, lane j (< 16) holds column j of the inverse, the entries of T are LDS broadcasts.  The
+        // row tasks then solve with MFMA only -- X_q = R_q T_q^{-T} -- instead of a one-wave substitution.
+        __syncthreads();
+        {
+            const int o = 16 * wave;
+            double wv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double sacc = (r == (lane & 15)) ? 1.0 : 0.0;
+#pragma unroll
+                for (int c = 0; c < r; ++c) sacc -= U[(o + c) * ST_ULD + o + r] * wv[c];
+                const double trr = U[(o + r) * ST_ULD + o + r];
+                double rp = __builtin_amdgcn_rcp(trr);
+                rp = rp * (2.0 - trr * rp);
+                rp = rp * (2.0 - trr * rp);
+                wv[r] = sacc * rp;          // rows above the diagonal come out as exact zeros (zero right-hand side so far)
+            }
+            // Tinv_w(r, j) at tinv[slot][w][j][r]: the [k][i] image the consumers' MFMA A operand reads
+            double* __restrict__ out = tinv + (int64_t)t.slot * 1024 + wave * 256 + (lane & 15) * 16;
+            if (lane < 16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[r] = wv[r];
+            }
+        }
+        // publish: EVERY storing wave drains, the barrier collects them, then ONE device-scope release by lane 0 and
         // the flag (the explicit waits keep the order whatever the compiler does with the fence's own wait)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
+        __syncthreads();
+        if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flags + t.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -840,6 +884,49 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    if (!LU) {
+        // X <- R D^{-T} with MFMA only, per wave (its 16 rows are independent of the other waves'): for every 16-column
+        // block q   X_q = R_q T_q^{-T}   (A operand = the block's inverse, B operand = R_q as it sits in the registers),
+        // then   R_q' -= X_q L(q', q)^T  for the blocks q' to the right (A operand = -L from Dt, B operand = X_q)
+        double* __restrict__ Tl = smem + NB * NB;
+        {
+            double dv[NB * NB / 256], tv[4];
+#pragma unroll
+            for (int i = 0; i < NB * NB / 256; ++i) {       // all loads in flight (clamped addresses), then select + store
+                const int e = tid + 256 * i, k = e / NB, j = e % NB;
+                dv[i] = Dg[min(j, b - 1) + (int64_t)min(k, b - 1) * ld];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tv[i] = tinv[(int64_t)t.slot * 1024 + tid + 256 * i];
+#pragma unroll
+            for (int i = 0; i < NB * NB / 256; ++i) {
+                const int e = tid + 256 * i, k = e / NB, j = e % NB;
+                Dt[k][j] = (j < b && k < j) ? dv[i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Tl[tid + 256 * i] = tv[i];
+        }
+        __syncthreads();
+        const int ci = 16 * wave + fr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[q * 256 + (4 * sg + fk) * 16 + fr], rt[q][sg], x, 0, 0, 0);
+#pragma unroll
+            for (int qq = q + 1; qq < 4; ++qq)
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg)
+                    rt[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Dt[16 * q + 4 * sg + fk][16 * qq + fr], x[sg], rt[qq], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cj = 16 * q + fk + 4 * r;
+                if (ci < nrows && cj < b) Ag[ci + (int64_t)cj * ld] = x[r];
+            }
+        }
+        return;
+    }
     {
         double dv[NB * NB / 256];
 #pragma unroll
@@ -914,10 +1001,10 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     }
 }
 
-void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, hipStream_t st) {
+void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, hipStream_t st) {
     if (ntasks <= 0) return;
-    if (lu) hipLaunchKernelGGL(k_step<true>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info);
-    else hipLaunchKernelGGL(k_step<false>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info);
+    if (lu) hipLaunchKernelGGL(k_step<true>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv);
+    else hipLaunchKernelGGL(k_step<false>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv);
 }
 
 // relative map of every scatter problem: one workgroup per problem, lanes stride over its M source rows
