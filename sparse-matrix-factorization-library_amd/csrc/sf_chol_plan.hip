@@ -338,8 +338,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // the three-launch form -- stream-K GEMM, one-wave POTRF, 256-row TRSM workgroups -- has the better throughput.
     // Measured: 128^3 608 ms at 2048, 603 at 8192, 600 at 16384, 602 unlimited; 2-D 1000^2 (config 3) 12.0 ms up to 16384,
     // 12.3 at 32768, 13.3 unlimited
-    // (LU: k_step<true> still solves by substitution, 2 workgroups per CU: 93 ms at 2048 vs 95 at 16384 on config 5)
-    const int64_t fuse_max = (lu ? 4 : 32) * sf::GEMM_GRID;
+    // (LU config 5: 91.7 ms at 2048, 91.2 at 16384)
+    const int64_t fuse_max = 32 * sf::GEMM_GRID;
     for (int ph = 0; ph < 2; ++ph) {
     if (ph == 1) p->launch_split = p->launches.size();
     std::vector<std::vector<sf_long>> by_level(nlevels);
@@ -639,7 +639,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         {
             std::vector<int> zeros(std::max<int32_t>(n_flags, 1), 0);
             if ((rc = upload(&p->d_flags, zeros, &p->bytes_device))) break;
-            const size_t tb = (size_t)std::max<int64_t>(max_diag_tasks, 1) * 1024 * sizeof(double);
+            const size_t tb = (size_t)std::max<int64_t>(max_diag_tasks, 1) * (lu ? 2048 : 1024) * sizeof(double);
             if (hipMalloc((void**)&p->d_tinv, tb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += tb;
         }

@@ -65,7 +65,7 @@ struct StepTask {   // fused 64-column step on rows [row0, row0+nrows) of panel 
     int32_t row0, nrows;    // row0 == diag: the diagonal block (POTRF / GETRF, publishes `flag`); else rows below it (wait for `flag`)
     int32_t flag;           // index of this (panel, step)'s flag
     int32_t mode;           // bit 0: the triangular block has an implicit unit diagonal (LU: U12^T <- U12^T L11^{-T})
-    int32_t slot;           // Cholesky: index (within the launch) of the diagonal task whose 16 x 16 inverses the rows use
+    int32_t slot;           // index (within the launch) of the diagonal task whose 16 x 16 inverses the rows use
     int32_t pad;
 };
 
@@ -84,7 +84,7 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st)
 // tasks: the diagonal blocks first, then the 64-row tiles below them; at most GEMM_GRID tasks (all resident at once);
 // flags[task.flag] == epoch once that diagonal block is factored
 // lu != 0: the diagonal tasks hold (L panel, U^T panel) and are factored without pivoting
-// tinv: scratch for the 16 x 16 inverses, 1024 doubles per diagonal task of the launch (Cholesky)
+// tinv: scratch for the 16 x 16 inverses, 1024 (Cholesky) / 2048 (LU: of U11^T, then of L11) doubles per diagonal task of the launch
 void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, hipStream_t st);
 // One-time (plan creation): relative maps of all scatter problems [first, first+count) -- the device form of the
 // reference's createRelativeMap (cuda_kernel.cu:42-60): RelMap[map_off + ci] = position of source row ci in the

@@ -617,21 +617,19 @@ constexpr int ST_XLD = ST_ROWS + 16;     // its LDS row stride
 constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 
 template <bool LU>
-__global__ void __launch_bounds__(256, LU ? 2 : 3)
+__global__ void __launch_bounds__(256, LU ? 2 : 3)   // LU: the unblocked GETRF keeps a 64-value row per lane
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info,
        double* __restrict__ tinv) {
     // ONE LDS array, re-used by the phases of a task:
     //   update:            X staging buffers Xs[2][32][80]
     //   diagonal task:     U[c][r], the updated block (POTRF / GETRF works on it)
-    //   row task, Cholesky: Dt[k][j] = L(j,k) | Tl[4][16][16], the inverses of the four 16 x 16 diagonal sub-blocks
-    //   row task, LU:      U[c][r] | Dt[k][j]   (substitution solve)
-    constexpr int SMEM = LU ? (NB * ST_ULD + NB * NB) : (2 * ST_KC * ST_XLD);
+    //   row task:          Dt[k][j] = D(j,k) | Tl[4][16][16], the inverses of the four 16 x 16 diagonal sub-blocks of D
+    constexpr int SMEM = 2 * ST_KC * ST_XLD;
     __shared__ __attribute__((aligned(16))) double smem[SMEM];
-    __shared__ double Dinv[NB];
     static_assert(NB == ST_ROWS && NB == 64, "one wavefront per 64 x 64 tile");
-    static_assert(2 * ST_KC * ST_XLD <= SMEM && NB * ST_ULD <= SMEM && NB * NB + 4 * 256 <= SMEM, "phases must fit the LDS array");
+    static_assert(NB * ST_ULD <= SMEM && NB * NB + 4 * 256 <= SMEM, "phases must fit the LDS array");
     double* __restrict__ U = smem;
-    double (*Dt)[NB] = reinterpret_cast<double (*)[NB]>(LU ? smem + NB * ST_ULD : smem);
+    double (*Dt)[NB] = reinterpret_cast<double (*)[NB]>(smem);
 
     const StepTask t = tasks[blockIdx.x];
     const bool is_diag = t.row0 == t.diag;
@@ -703,10 +701,10 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         }
     }
 
-    // Cholesky row task: the updated tile stays in the MFMA accumulator layout (wave w: rows 16 w + fr, column tile q:
+    // Row task: the updated tile stays in the MFMA accumulator layout (wave w: rows 16 w + fr, column tile q:
     // columns 16 q + fk + 4 r), which is also the B-operand layout of the next MFMA -- the solve below runs on registers
     double4_t rt[4];
-    if (!LU && !is_diag) {
+    if (!is_diag) {
         const int ci = 16 * wave + fr, cic = min(ci, nrows - 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -719,7 +717,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     }
     // accumulators -> U[cj][ci] = A(ci, cj) - update (padded with the identity / zeros); the staging buffers are dead
     // (the chunk loop ends with a barrier)
-    if (LU || is_diag) {
+    if (is_diag) {
         const int ci = 16 * wave + fr;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -744,7 +742,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 
     if (LU && is_diag) {
         __syncthreads();
-        if (wave != 0) return;
+        if (wave == 0) {
         // no-pivot LU of the updated block (k_getrf_block's scheme): lane r holds row r, multipliers l(r,j) = a(r,j) / pivot
         // with the reciprocal from v_rcp_f64 + two Newton steps (the IEEE divide sequence sits on the 64-step critical path)
         double a[NB];
@@ -770,9 +768,39 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             if (lane < b && c < b) {
                 if (c < lane) Ag[lane + (int64_t)c * ld] = a[c]; else PUd[c + (int64_t)lane * ld] = a[c];
             }
+            U[c * ST_ULD + lane] = a[c];        // the factored block (L below, U on and above the diagonal; identity padding)
+        }
+        }
+        __syncthreads();
+        {
+            // inverses of the 16 x 16 diagonal sub-blocks the row tasks solve against: of U11^T (lower, for the L rows) at
+            // tinv[slot][0][w], of the unit-lower L11 (for the U^T rows) at tinv[slot][1][w]; wave w does block w of both
+            const int o = 16 * wave, j = lane & 15;
+            double wu[16], wl[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double su = (r == j) ? 1.0 : 0.0, sl = su;
+#pragma unroll
+                for (int c = 0; c < r; ++c) {
+                    su -= U[(o + r) * ST_ULD + o + c] * wu[c];      // U11^T(r,c) = U11(c,r): row o+c, column o+r of the block
+                    sl -= U[(o + c) * ST_ULD + o + r] * wl[c];      // L11(r,c): row o+r, column o+c
+                }
+                const double trr = U[(o + r) * ST_ULD + o + r];
+                double rp = __builtin_amdgcn_rcp(trr);
+                rp = rp * (2.0 - trr * rp);
+                rp = rp * (2.0 - trr * rp);
+                wu[r] = su * rp;
+                wl[r] = sl;
+            }
+            double* __restrict__ out = tinv + (int64_t)t.slot * 2048 + wave * 256 + j * 16;
+            if (lane < 16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { out[r] = wu[r]; out[1024 + r] = wl[r]; }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
+        __syncthreads();
+        if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flags + t.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -884,11 +912,13 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (!LU) {
+    {
         // X <- R D^{-T} with MFMA only, per wave (its 16 rows are independent of the other waves'): for every 16-column
         // block q   X_q = R_q T_q^{-T}   (A operand = the block's inverse, B operand = R_q as it sits in the registers),
-        // then   R_q' -= X_q L(q', q)^T  for the blocks q' to the right (A operand = -L from Dt, B operand = X_q)
+        // then   R_q' -= X_q D(q', q)^T  for the blocks q' to the right (A operand = -D from Dt, B operand = X_q).
+        // D = L11 (Cholesky), U11^T (LU, L rows) or the unit-lower L11 (LU, U^T rows: mode bit 0)
         double* __restrict__ Tl = smem + NB * NB;
+        const double* __restrict__ tsrc = tinv + (int64_t)t.slot * (LU ? 2048 : 1024) + ((LU && (t.mode & 1)) ? 1024 : 0);
         {
             double dv[NB * NB / 256], tv[4];
 #pragma unroll
@@ -897,7 +927,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 dv[i] = Dg[min(j, b - 1) + (int64_t)min(k, b - 1) * ld];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tv[i] = tinv[(int64_t)t.slot * 1024 + tid + 256 * i];
+            for (int i = 0; i < 4; ++i) tv[i] = tsrc[tid + 256 * i];
 #pragma unroll
             for (int i = 0; i < NB * NB / 256; ++i) {
                 const int e = tid + 256 * i, k = e / NB, j = e % NB;
@@ -925,79 +955,6 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 if (ci < nrows && cj < b) Ag[ci + (int64_t)cj * ld] = x[r];
             }
         }
-        return;
-    }
-    {
-        double dv[NB * NB / 256];
-#pragma unroll
-        for (int i = 0; i < NB * NB / 256; ++i) {       // all 16 loads in flight (clamped addresses), then select + store
-            const int e = tid + 256 * i, k = e / NB, j = e % NB;
-            dv[i] = Dg[min(j, b - 1) + (int64_t)min(k, b - 1) * ld];
-        }
-#pragma unroll
-        for (int i = 0; i < NB * NB / 256; ++i) {
-            const int e = tid + 256 * i, k = e / NB, j = e % NB;
-            Dt[k][j] = (j < b && k < j) ? dv[i] : 0.0;
-        }
-    }
-    if (tid < NB) {
-        const double dd = Dg[min(tid, b - 1) + (int64_t)min(tid, b - 1) * ld];
-        Dinv[tid] = (tid < b && !(t.mode & 1)) ? 1.0 / dd : 1.0;      // mode bit 0: unit diagonal
-    }
-    __syncthreads();
-
-    // X <- X D^{-T}, blocked by 16 columns: wave 0 solves the 16 columns of block q by substitution (lane = row),
-    // then every wave updates its 16 rows of the columns to the right with MFMA:
-    //   U[cj][ci] -= sum_k D(cj,k) X(ci,k),  k in block q  (A operand = -Dt, B operand = X from U)
-#pragma unroll 1
-    for (int q = 0; q < NB / 16; ++q) {
-        const int c0 = q * 16;
-        if (c0 >= b) break;
-        if (wave == 0) {
-            // two 8-column register blocks (the shape k_trsm_block uses; a 16-wide block makes the compiler spill)
-#pragma unroll 1
-            for (int jb = c0; jb < c0 + 16; jb += 8) {
-                double x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = U[(jb + u) * ST_ULD + lane];
-                for (int k = c0; k < jb; ++k) {
-                    const double xk = U[k * ST_ULD + lane];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] -= xk * Dt[k][jb + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                    for (int v = 0; v < u; ++v) x[u] -= x[v] * Dt[jb + v][jb + u];
-                    x[u] *= Dinv[jb + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    U[(jb + u) * ST_ULD + lane] = x[u];
-                    if (lane < nrows && jb + u < b) Ag[lane + (int64_t)(jb + u) * ld] = x[u];
-                }
-            }
-        }
-        __syncthreads();
-        if (c0 + 16 < b) {
-            const int ci = wave * 16 + fr;                  // this wave's 16 rows
-            double xf[4];
-#pragma unroll
-            for (int sgm = 0; sgm < 4; ++sgm) xf[sgm] = U[(c0 + 4 * sgm + fk) * ST_ULD + ci];    // B[k][j = ci]
-            for (int ct = q + 1; ct < NB / 16; ++ct) {
-                const int cb = ct * 16;
-                if (cb >= b) break;
-                double4_t d;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d[r] = U[(cb + fk + 4 * r) * ST_ULD + ci];            // D[i = cj][j = ci]
-#pragma unroll
-                for (int sgm = 0; sgm < 4; ++sgm)
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(-Dt[c0 + 4 * sgm + fk][cb + fr], xf[sgm], d, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) U[(cb + fk + 4 * r) * ST_ULD + ci] = d[r];
-            }
-        }
-        __syncthreads();
     }
 }
 
