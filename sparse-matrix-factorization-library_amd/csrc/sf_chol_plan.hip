@@ -40,6 +40,7 @@ namespace {
 
 struct Launch {
     int kind;       // 0 potrf, 1 trsm, 2 gemm panel (inner, K = NB), 3 gemm scatter, 4 gemm panel (outer, large K),
+                    // 6 Schur updates with K <= SU_MAXK (k_update_small, tasks in stasks),
                     // 5 fused step k_step (Cholesky, steps of at most GEMM_GRID workgroups; otherwise and for LU: 2, 0, 1)
     int64_t first;  // first task
     int count;
@@ -136,12 +137,14 @@ struct sf_chol_plan {
     int epoch = 0;
     GemmProb* d_probs = nullptr;
     GemmTask* d_gtasks = nullptr;
+    GemmTask* d_stasks = nullptr;   // tiles of k_update_small
     uint32_t* d_ktprefix = nullptr;
     int32_t* d_relmap = nullptr;
 
     std::vector<Launch> launches;
     int nlevels = 0;
     int64_t n_gemm_tasks = 0, n_pairs = 0;
+    double flops_update_small = 0;      // part of flops_update done by k_update_small (K <= SU_MAXK)
     double flops_exec = 0, flops_update = 0, scatter_elems = 0, flops_panel_gemm = 0, flops_outer_gemm = 0;
     size_t bytes_device = 0;
     bool values_set = false;
@@ -187,7 +190,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
-                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_ktprefix,
+                    p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
                     p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x, p->d_relmap, p->d_scratch};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -313,6 +316,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     std::vector<StepTask> steps;
     std::vector<GemmProb> probs;
     std::vector<GemmTask> gtasks;
+    std::vector<GemmTask> stasks;           // 64 x 32 tiles of the Schur updates with K <= SU_MAXK (k_update_small)
     int64_t relmap_size = 0;
     std::vector<int64_t> scatter_probs;     // index of the first problem of every (s, a) pair
     // Tiles of one problem are emitted in "supertile" order: blocks of (up to) 8 tile columns x 8 tile rows.
@@ -495,7 +499,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             }
         }
         // Schur updates of every supernode of this level into its ancestors
-        const int64_t g0 = (int64_t)gtasks.size();
+        const int64_t g0 = (int64_t)gtasks.size(), s0 = (int64_t)stasks.size();
+        double level_small_flops = 0;
         for (sf_long s : Sl) {
             const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
             const sf_long* rows = Lsi + Lsip[s];
@@ -526,13 +531,23 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     g.c_off = XP[a] + (side ? ushift : 0);
                     g.strict = (lu && !side) ? 1 : 0;
                     probs.push_back(g);
-                    add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                    if (g.K <= sf::SU_MAXK) {
+                        // short inner dimension: one wave per 64 x 32 tile (k_update_small); tiles entirely above the diagonal are skipped
+                        const int tmn = (g.M + sf::SU_TM - 1) / sf::SU_TM, tnn = (g.N + sf::SU_TN - 1) / sf::SU_TN;
+                        for (int tn = 0; tn < tnn; ++tn)
+                            for (int tm = 0; tm < tmn; ++tm)
+                                if ((tm + 1) * sf::SU_TM - 1 >= tn * sf::SU_TN)
+                                    stasks.push_back(GemmTask{(int32_t)probs.size() - 1, (uint16_t)tm, (uint16_t)tn});
+                    } else {
+                        add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                    }
                 }
                 // executed flops of the tiles' useful part: Cholesky dn(dn+1)dk + 2 dm dn dk; LU twice minus the
                 // diagonal the L side skips (the reference's two GEMMs do 2(dn+dm)dn dk + 2 dm dn dk, L:2570-2577)
                 const double fl = lu ? (2.0 * (double)dnm * dn * nk + 2.0 * (double)(dnm - dn) * dn * nk)
                                      : ((double)dn * (dn + 1) * nk + 2.0 * (double)(dnm - dn) * dn * nk);
                 p->flops_update += fl;
+                if (g.K <= sf::SU_MAXK) { p->flops_update_small += fl; level_small_flops += fl; }
                 p->flops_exec += fl;
                 p->scatter_elems += lu ? ((double)dnm * dn + (double)(dnm - dn) * dn)
                                        : ((double)dn * (dn + 1) / 2.0 + (double)(dnm - dn) * dn);
@@ -544,10 +559,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             p->launches.push_back(Launch{3, g0, (int)(gtasks.size() - g0)});
             p->launches.back().split = (ph == 1 && nranks > 1);
         }
+        if ((int64_t)stasks.size() > s0) {
+            p->launches.push_back(Launch{6, s0, (int)(stasks.size() - s0)});
+            p->launches.back().split = (ph == 1 && nranks > 1);
+            p->launches.back().flops = level_small_flops;
+        }
     }
     }   // phases
     if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
-    p->n_gemm_tasks = (int64_t)gtasks.size();
+    p->n_gemm_tasks = (int64_t)gtasks.size() + (int64_t)stasks.size();
 
     // ---------------- device solve schedule (unsharded plans) ----------------
     std::vector<sf::SolveTask> solve;
@@ -645,6 +665,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
         if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
+        if ((rc = upload(&p->d_stasks, stasks, &p->bytes_device))) break;
         if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
         {   // relative maps of all Schur updates, built on the device (createRelativeMap, CK:42-60, once per plan)
             const size_t mb = (size_t)std::max<int64_t>(relmap_size, 1) * sizeof(int32_t);
@@ -816,6 +837,12 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 else sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st);
                 break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
+            case 6: {       // k_update_small; a split launch (distributed top): this rank's share of the tiles (the update is a sum)
+                int64_t lo = 0, hi = L.count;
+                if (L.split) { lo = (int64_t)L.count * p->rank / p->nranks; hi = (int64_t)L.count * (p->rank + 1) / p->nranks; }
+                sf::launch_update_small(p->d_probs, p->d_stasks + L.first + lo, (int)(hi - lo), p->d_Lsx, p->d_relmap, st);
+                break;
+            }
             case 5: sf::launch_step(p->d_steps + L.first, L.count, p->lu ? 1 : 0, p->d_Lsx, p->d_flags, p->epoch, p->d_info, p->d_tinv, st); break;
             case 2:
             case 3:
@@ -847,7 +874,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         if (dump && first) fprintf(dump, "launch,kind,tasks,units,flops,ms\n");
         for (size_t k = 0; k + 1 < evs.size(); ++k) {
             if (hipEventElapsedTime(&ms, evs[k], evs[k + 1]) != hipSuccess) continue;
-            if (kinds[k] == 3) p->last_update_ms += ms; else p->last_panel_ms += ms;
+            if (kinds[k] == 3) p->last_update_ms += ms; else if (kinds[k] != 6) p->last_panel_ms += ms;
             p->last_kind_ms[kinds[k]] += ms;
             if (dump) {
                 const Launch& L = p->launches[l0 + k];
@@ -1024,6 +1051,8 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     if (k == "last_inner_gemm_ms") return p->last_kind_ms[2];
     if (k == "last_outer_gemm_ms") return p->last_kind_ms[4];
     if (k == "last_step_ms") return p->last_kind_ms[5];
+    if (k == "last_small_update_ms") return p->last_kind_ms[6];
+    if (k == "flops_update_small") return p->flops_update_small;
     if (k == "flops_outer_gemm") return p->flops_outer_gemm;
     return -1;
 }

@@ -15,6 +15,8 @@ constexpr int GEMM_BK = 16;
 constexpr int GEMM_WAVES = 8;     // waves per GEMM workgroup (2 along ci x GEMM_WAVES/2 along cj)
 constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
 constexpr int GEMM_GRID = 512;   // persistent GEMM grid: 2 workgroups per CU x 256 CUs
+constexpr int SU_TM = 64, SU_TN = 32;   // tile of k_update_small (one wave): rows x columns
+constexpr int SU_MAXK = 64;      // Schur updates with K <= SU_MAXK go to k_update_small
 
 // One C -= Y * X^T problem on rows of ONE source panel (column-major, leading dimension lda):
 //   C[ci][cj] = sum_k src[y_off + ci + k*lda] * src[x_off + cj + k*lda],   0<=ci<M, 0<=cj<N, 0<=k<K
@@ -95,6 +97,9 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
 // this call executes the units [u_lo, u_hi) of the launch
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
                  int mode, double* Lsx, const int32_t* RelMap, hipStream_t st);
+
+// Schur updates with K <= SU_MAXK: tasks are SU_TM x SU_TN tiles (GemmTask.tm / .tn in those units), one wave each
+void launch_update_small(const GemmProb* probs, const GemmTask* tasks, int ntasks, double* Lsx, const int32_t* RelMap, hipStream_t st);
 
 // ---- device-side supernodal triangular solves with the resident factor (reference: scalar host loops,
 // Cholesky/Source/SparseFrame.c:3074-3134).  64-column block steps, the same (level, step) sweep as the factorization.
