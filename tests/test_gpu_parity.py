@@ -219,16 +219,16 @@ def test_sharded_plans_emulated_ranks_on_one_gpu(oracle, world):
         e.close()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_distributed_top_emulated_ranks_on_one_gpu(oracle, world):
+@pytest.mark.parametrize("N,world", [(24, 2), (24, 3), (24, 8), (10, 8)])
+def test_distributed_top_emulated_ranks_on_one_gpu(oracle, N, world):
     """distributed top (sf_chol_plan_create_distributed) with every rank's plan on the single test GPU: phase 0,
     then per segment the regions are summed through torch tensors aliasing the plans' device memory (the RCCL
     all-reduce between GPUs) and every rank runs the segment with ITS share of the split GEMM launches.
-    24^3: the root separator has 576 > 512 columns, so a split left-looking outer GEMM is part of the run."""
+    24^3: the root separator has 576 > 512 columns, so a split left-looking outer GEMM is part of the run.
+    10^3 on 8 ranks: top separators of 25 and 50 columns, so split k_update_small launches (K <= 64) are part of it."""
     import torch
     from importlib import import_module
     sharded = import_module("sparse-matrix-factorization-library_amd.sharded")
-    N = 24
     n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
     sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 1 << 30)
     owner, tf, ml = sf.subtree_partition(sym, world, 1.0 / world + sharded.TOP_CHAIN_SHARE)
@@ -236,7 +236,7 @@ def test_distributed_top_emulated_ranks_on_one_gpu(oracle, world):
     assert ntop > 0
     engines = [sharded.HipEngine(sym, sf.phases_for_rank(owner, r), r == 0, 0, r, world, True) for r in range(world)]
     nseg = engines[0].num_segments()
-    assert nseg >= 2 and all(e.num_segments() == nseg for e in engines)
+    assert nseg >= (2 if N >= 24 else 1) and all(e.num_segments() == nseg for e in engines)
     ref, info, _ = oracle.chol_factorize(sym)
     for rep in range(2):                                   # plans are reusable
         for e in engines:
