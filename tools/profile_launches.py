@@ -1,3 +1,6 @@
+"""Per-launch timing of one 128^3 factorization (HIP events around every launch, SF_PROFILE_DUMP csv):
+    python tools/profile_launches.py   ->  gpurun_out/launches.csv  (launch, kind, tasks, units, flops, ms)
+kinds: 0 POTRF, 1 TRSM, 2 inner GEMM, 3 Schur (k_gemm<1>), 4 outer GEMM, 5 fused step (k_step), 6 small Schur (k_update_small)."""
 import importlib, os, sys
 sys.path.insert(0, os.getcwd())
 sf = importlib.import_module("sparse-matrix-factorization-library_amd")
