@@ -323,16 +323,23 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // The kernel hands each XCD a contiguous run of tasks, so the ~64 workgroups resident on one XCD at a
     // time work on one supertile and march through K together: per K step they touch 8 + 8 operand slices
     // instead of 1 + 64, i.e. each slice is fetched into that XCD's L2 once and re-used 8 times.
-    auto add_tiles = [&](int32_t prob_id, int M, int N) {
+    // A task = one tile over one slice of its problem's K range, emitted slice by slice (the kernel deals consecutive tasks
+    // out in rounds, so a round would be 512 adjacent tiles over the SAME K range).  Measured at 128^3 on one box: no
+    // slicing 556 ms; slices of 512 / 256 / 128 steps 563 / 569 / 569 ms -- every extra slice is one more atomic pass over
+    // the target tile, which costs more than the extra rounds gain.  GEMM_SLICE is therefore "never" (one slice).
+    const int gemm_slice = sf::GEMM_SLICE;
+    auto add_tiles = [&](int32_t prob_id, int M, int N, int K) {
         const int tmn = (M + sf::GEMM_BM - 1) / sf::GEMM_BM, tnn = (N + sf::GEMM_BN - 1) / sf::GEMM_BN;
         const int sw = std::min(tnn, 8), sh = std::max(1, 64 / sw);
+        const int nkt_all = (K + sf::GEMM_BK - 1) / sf::GEMM_BK;
+        for (int k0 = 0; k0 < nkt_all; k0 += gemm_slice)
         for (int sj = 0; sj < tnn; sj += sw)
             for (int si = 0; si < tmn; si += sh)
                 for (int tn = sj; tn < std::min(sj + sw, tnn); ++tn)
                     for (int tm = si; tm < std::min(si + sh, tmn); ++tm) {
                         // keep tiles that contain at least one element with ci >= cj
                         if ((tm + 1) * sf::GEMM_BM - 1 < tn * sf::GEMM_BN) continue;
-                        gtasks.push_back(GemmTask{prob_id, (uint16_t)tm, (uint16_t)tn});
+                        gtasks.push_back(GemmTask{prob_id, (uint16_t)tm, (uint16_t)tn, (uint32_t)k0, (uint32_t)std::min(gemm_slice, nkt_all - k0)});
                     }
     };
 
@@ -381,7 +388,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         p->flops_outer_gemm += fl;
                         p->flops_panel_gemm += fl;
                         probs.push_back(g);
-                        add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                        add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K);
                     }
                 }
                 if ((int64_t)gtasks.size() > g0) {
@@ -478,7 +485,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                             g.strict = (lu && !side) ? 1 : 0;
                             p->flops_panel_gemm += (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
                             probs.push_back(g);
-                            add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                            add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K);
                         }
                     }
                     potrf.push_back(PotrfTask{XP[s], nsrow, diag, b, 0});
@@ -537,9 +544,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         for (int tn = 0; tn < tnn; ++tn)
                             for (int tm = 0; tm < tmn; ++tm)
                                 if ((tm + 1) * sf::SU_TM - 1 >= tn * sf::SU_TN)
-                                    stasks.push_back(GemmTask{(int32_t)probs.size() - 1, (uint16_t)tm, (uint16_t)tn});
+                                    stasks.push_back(GemmTask{(int32_t)probs.size() - 1, (uint16_t)tm, (uint16_t)tn, 0u, 0u});
                     } else {
-                        add_tiles((int32_t)probs.size() - 1, g.M, g.N);
+                        add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K);
                     }
                 }
                 // executed flops of the tiles' useful part: Cholesky dn(dn+1)dk + 2 dm dn dk; LU twice minus the
@@ -615,7 +622,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             ktprefix.push_back((uint32_t)run);
             const int32_t pi = gtasks[L.first + k].prob;
             const GemmProb& g = probs[pi];
-            run += (uint64_t)((g.K + sf::GEMM_BK - 1) / sf::GEMM_BK);
+            run += (uint64_t)gtasks[L.first + k].nkt;
             if (pi != last_prob) {      // tasks of one problem are contiguous
                 L.flops += (double)g.N * (g.N + 1) * g.K + 2.0 * (double)(g.M - g.N) * g.N * g.K;
                 last_prob = pi;

@@ -15,6 +15,7 @@ constexpr int GEMM_BK = 16;
 constexpr int GEMM_WAVES = 8;     // waves per GEMM workgroup (2 along ci x GEMM_WAVES/2 along cj)
 constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
 constexpr int GEMM_GRID = 512;   // persistent GEMM grid: 2 workgroups per CU x 256 CUs
+constexpr int GEMM_SLICE = 1 << 30;  // K steps per task (a tile's K range could be cut into slices; measured: it does not pay)
 constexpr int SU_TM = 64, SU_TN = 32;   // tile of k_update_small (one wave): rows x columns
 constexpr int SU_MAXK = 64;      // Schur updates with K <= SU_MAXK go to k_update_small
 
@@ -40,9 +41,11 @@ struct GemmProb {
     int64_t map_off;        // scatter mode: offset of this (source, ancestor) pair's relative map (M entries) in RelMap
 };
 
-struct GemmTask {   // one 128x128 tile
+struct GemmTask {   // one 128x128 tile of a problem over ONE slice of its K range (k_update_small: a 64x32 tile, whole K)
     int32_t prob;
     uint16_t tm, tn;    // tile coordinates along ci / cj
+    uint32_t kt0;       // first 16-deep K step of the slice
+    uint32_t nkt;       // K steps in the slice
 };
 
 struct PotrfTask {  // factor the b x b diagonal block at (diag, diag) of a panel

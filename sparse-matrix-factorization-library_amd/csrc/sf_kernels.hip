@@ -446,11 +446,37 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         const uint32_t b = blockIdx.x, q = G >> 3, r = G & 7, x = b & 7;
         share = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
-    const uint32_t U = (T + G - 1) / G;
-    if (share * U >= T) return;
-    uint32_t u = u_lo + share * U;
-    const uint32_t u_end = min(u_hi, u + U);
-    int ti = last_le_u32(kt_prefix, ntasks + 1, u);
+    // Whole tiles are dealt out in ROUNDS: in round r workgroup `share` takes tile t0 + r G + share, so the 64 workgroups
+    // of an XCD (consecutive shares) work on 64 CONSECUTIVE tiles -- one supertile -- at the same time and march through K
+    // together: each operand slice is fetched into that XCD's L2 once per round and re-used by the 8 tiles of its
+    // row / column.  (Contiguous shares of ~16 tiles each, the plain stream-K split, put concurrently running
+    // workgroups 16 tiles apart: no operand was ever shared, PMC FETCH_SIZE = the no-reuse byte count.)
+    // What does not fill a round -- the partial tiles at the ends of a rank's unit window and the last < G tiles -- is
+    // split by (tile, K step) units as before, so the tail is still balanced.
+    (void)T;
+    int t0 = last_le_u32(kt_prefix, ntasks + 1, u_lo);
+    if (kt_prefix[t0] < u_lo) ++t0;
+    const int t1 = last_le_u32(kt_prefix, ntasks + 1, u_hi);          // tiles [t0, t1) lie inside [u_lo, u_hi)
+    const int R = (t1 > t0) ? (int)((uint32_t)(t1 - t0) / G) : 0;
+    const uint32_t head_end = (R > 0) ? kt_prefix[t0] : u_hi;
+    const uint32_t tail_beg = (R > 0) ? kt_prefix[t0 + R * (int)G] : u_hi;
+
+    for (int ph = 0; ph < R + 2; ++ph) {
+    uint32_t u, u_end;
+    int ti;
+    if (ph >= 1 && ph <= R) {
+        ti = t0 + (ph - 1) * (int)G + (int)share;
+        u = kt_prefix[ti];
+        u_end = kt_prefix[ti + 1];
+    } else {
+        const uint32_t ra = (ph == 0) ? u_lo : tail_beg, rb = (ph == 0) ? head_end : u_hi;
+        if (rb <= ra) continue;
+        const uint32_t U = (rb - ra + G - 1) / G;
+        if (share * U >= rb - ra) continue;
+        u = ra + share * U;
+        u_end = min(rb, u + U);
+        ti = last_le_u32(kt_prefix, ntasks + 1, u);
+    }
 
     while (u < u_end) {
         const GemmTask tk = tasks[ti];
@@ -463,10 +489,13 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         ++ti;
 
         const int ci0 = tk.tm * GEMM_BM, cj0 = tk.tn * GEMM_BN;
-        const int M = pb.M, N = pb.N, K = pb.K;
+        // the task covers the K steps [tk.kt0, tk.kt0 + nkt) of its tile: operand pointers and K are those of the slice
+        const int M = pb.M, N = pb.N;
         const int lda = pb.lda;
-        const double* __restrict__ Yg = Lsx + pb.y_off + ci0;
-        const double* __restrict__ Xg = Lsx + pb.x_off + cj0;
+        const int kfirst = (int)tk.kt0 * GEMM_BK;
+        const int K = min(pb.K - kfirst, nkt * GEMM_BK);
+        const double* __restrict__ Yg = Lsx + pb.y_off + ci0 + (int64_t)kfirst * lda;
+        const double* __restrict__ Xg = Lsx + pb.x_off + cj0 + (int64_t)kfirst * lda;
 
         if (MODE == 1) {
             // relative map of this tile's rows/columns inside the target panel (precomputed once per plan)
@@ -591,6 +620,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         // the next tile re-uses the LDS buffers and the relative maps
         __syncthreads();
     }
+    }   // phases
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -32,15 +32,18 @@ int main(int argc, char** argv) {
     std::vector<sf::GemmTask> tasks;
     const int tmn = (M + sf::GEMM_BM - 1) / sf::GEMM_BM, tnn = (N + sf::GEMM_BN - 1) / sf::GEMM_BN;
     const int sw = std::min(tnn, 8), sh = std::max(1, 64 / sw);
+    const int nkt_all = (K + sf::GEMM_BK - 1) / sf::GEMM_BK;
+    for (int k0 = 0; k0 < nkt_all; k0 += sf::GEMM_SLICE)
     for (int sj = 0; sj < tnn; sj += sw)
         for (int si = 0; si < tmn; si += sh)
             for (int tn = sj; tn < std::min(sj + sw, tnn); ++tn)
                 for (int tm = si; tm < std::min(si + sh, tmn); ++tm) {
                     if ((tm + 1) * sf::GEMM_BM - 1 < tn * sf::GEMM_BN) continue;
-                    tasks.push_back(sf::GemmTask{0, (uint16_t)tm, (uint16_t)tn});
+                    tasks.push_back(sf::GemmTask{0, (uint16_t)tm, (uint16_t)tn, (uint32_t)k0, (uint32_t)std::min(sf::GEMM_SLICE, nkt_all - k0)});
                 }
     std::vector<uint32_t> pre(tasks.size() + 1);
-    for (size_t i = 0; i <= tasks.size(); ++i) pre[i] = (uint32_t)(i * (size_t)((K + sf::GEMM_BK - 1) / sf::GEMM_BK));
+    pre[0] = 0;
+    for (size_t i = 0; i < tasks.size(); ++i) pre[i + 1] = pre[i] + tasks[i].nkt;
     uint32_t* dpre;
     CK(hipMalloc(&dpre, pre.size() * sizeof(uint32_t)));
     CK(hipMemcpy(dpre, pre.data(), pre.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -50,7 +53,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(sf::GemmTask), hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double alg = (double)N * (N + 1) * K + 2.0 * (double)(M - N) * N * K;
-    const double exec = (double)tasks.size() * 128.0 * 128.0 * 2.0 * K;
+    const double exec = (double)pre.back() * 128.0 * 128.0 * 2.0 * sf::GEMM_BK;
     float best = 1e30f;
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0));
