@@ -870,7 +870,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                     if (lane < b && c0 + u <= lane) Ag[lane + (int64_t)(c0 + u) * ld] = a[u];
                 }
             }
-            if (q == NB / 16 - 1) break;
+            if (q == NB / 16 - 1 || c0 + 16 >= b) break;      // nothing but identity padding to the right (narrow panel)
             __syncthreads();
             if (wave > q) {
                 const int ci = wave * 16 + fr;                  // this wave's 16 rows
@@ -970,6 +970,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         const int ci = 16 * wave + fr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (16 * q >= b) break;                              // narrow panel: the remaining blocks are padding
             double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg)
