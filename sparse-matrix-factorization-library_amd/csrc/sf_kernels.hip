@@ -7,11 +7,16 @@
 //   k_getrf_block   : no-pivot LU of the block (magma_dgetrf_nopiv L:2653, cusolverDnDgetrf/NULL L:3344), same scheme
 //   k_trsm_block    : dtrsm_('R','L','C','N') of a row tile against that block (C:2142, C:2773); LU: D from the
 //                     other panel, optional unit diagonal (L:2660)
-//   k_gemm<mode>    : fp64 MFMA (v_mfma_f64_16x16x4_f64) C -= Y X^T on LDS-staged panels, persistent stream-K grid
+//   k_gemm<mode>    : fp64 MFMA (v_mfma_f64_16x16x4_f64) C -= Y X^T on LDS-staged panels, persistent grid (tiles in rounds
+//                     + stream-K remainder)
 //       mode 0 : in-panel updates (the reference's blocked-potrf SYRK/GEMM, C:2854-2863)
 //       mode 1 : Schur-complement update of an ancestor panel: dsyrk+dgemm (C:2061-2070; LU: L:2570-2577) with the
 //                mapped scatter-subtract (mappedSubtract, CK:62-124; CPU loops C:2073-2086, L:2583-2604) fused into
 //                the epilogue as native global_atomic_add_f64, lower trapezoid only
+//   k_update_small  : the mode-1 update for K <= 64 (bottom-level supernodes): one wave per 64x32 tile, no LDS
+//   k_step<LU>      : one 64-column step of the in-panel factorization in ONE launch: left-looking update (MFMA) +
+//                     POTRF / GETRF of the diagonal block + TRSM of the rows below (MFMA, from 16x16 inverses), with a
+//                     flag hand-off from the diagonal workgroup to the row workgroups inside the launch
 //   k_build_relmaps : createRelativeMap (CK:42-60), once per plan for every (descendant, ancestor) pair
 //   k_pack_lu       : gathers the device's (L, U^T) panel pairs into the reference's packed LU panels (L:2514-2517)
 //   k_solve_*       : level-scheduled triangular solves with the resident factor (host loops C:3074-3134)
@@ -412,11 +417,13 @@ __device__ __forceinline__ int last_le_u32(const uint32_t* __restrict__ a, int n
     return lo;
 }
 
-// Persistent "stream-K" launch: the work of one launch is the list of (tile, 16-deep K step) units of all
-// its tiles, in task order; kt_prefix[i] = number of units before tile i.  The grid is a fixed number of
-// workgroups (2 per CU); each takes one contiguous, equal share of the units, so that the chip stays full
-// whatever the mix of tile counts and K lengths in the launch (no tail of half-empty rounds).  A tile
-// whose K range is split between workgroups is combined with fp64 atomics in the epilogue.
+// Persistent launch: the work of one launch is the list of (tile, 16-deep K step) units of all its tiles, in
+// task order; kt_prefix[i] = number of units before tile i.  The grid is a fixed number of workgroups (2 per CU).
+// Whole tiles are dealt out in rounds (workgroup `share` takes tile r G + share in round r -- see the kernel body for
+// why that matters for the L2); what does not fill a round is split "stream-K" style: each workgroup takes one
+// contiguous, equal share of the remaining units, so the chip stays full whatever the mix of tile counts and K
+// lengths (no tail of half-empty rounds).  Every tile is combined into its target with fp64 atomics (a K range
+// split between workgroups needs them anyway).
 template <int MODE>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
