@@ -272,6 +272,20 @@ def test_distributed_top_emulated_ranks_on_one_gpu(oracle, N, world):
     # a distributed plan refuses the replicated phase-1 entry point
     with pytest.raises(RuntimeError):
         engines[0].plan.factorize_phase(1)
+    # packing a second segment before the first packed one has run, or running another segment than the packed one, is an error
+    engines[0].set_values(sym.Lx)
+    engines[0].factorize_phase(0)
+    engines[0].plan.segment_pack(0)
+    with pytest.raises(RuntimeError):
+        engines[0].plan.segment_pack(0)
+    if nseg > 1:
+        with pytest.raises(RuntimeError):
+            engines[0].plan.factorize_segment(1)
+    engines[0].plan.factorize_segment(0, sync=True)
+    # region queries: capacity too small / segment out of range
+    assert len(engines[0].plan.segment_regions(0)) >= 1
+    with pytest.raises(RuntimeError):
+        engines[0].plan.segment_regions(nseg)
     for e in engines:
         e.close()
 
