@@ -290,6 +290,25 @@ def test_distributed_top_emulated_ranks_on_one_gpu(oracle, N, world):
         e.close()
 
 
+@pytest.mark.parametrize("seed,n_,per_col,band", [(1, 1500, 3, None), (2, 4000, 2, None), (3, 3000, 6, 400), (4, 6000, 4, 60),
+                                                   (5, 800, 12, None), (6, 2500, 5, 1200)])
+def test_random_patterns_with_builtin_ordering(oracle, seed, n_, per_col, band):
+    """random SPD patterns (uniformly random: heavy fill and wide root supernodes; banded: chains of panels) ordered by the
+    built-in nested dissection -- irregular supernode widths, update shapes and tree depths through every kernel"""
+    n, Cp, Ci, Cx = gen.random_spd_lower(n_, per_col, seed=seed, bandwidth=band)
+    perm = sf.graph_nd_perm(n, Cp, Ci)
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, sf.REFERENCE_SLOT_1GPU)
+    plan, Lsx = gpu_factor(sym)
+    ref, info, _ = oracle.chol_factorize(sym)
+    assert info == 0
+    assert rel_err(Lsx, ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+    res, _ = oracle.chol_residual(sym, Lsx)
+    assert res <= TOL_RESIDUAL
+    b = 1.0 + np.arange(n) / n
+    assert sf.validate_solution(sym, plan.solve(b), b) <= 1e-12
+    plan.close()
+
+
 def test_rccl_world1_collectives_on_plan_memory():
     """the real RCCL backend on the plan's memory and stream (one-rank group; see tests/_nccl_world1_worker.py)"""
     import socket
