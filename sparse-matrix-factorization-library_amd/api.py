@@ -491,11 +491,16 @@ class MatrixInfo:
         check(self._lib.SparseFrame_read_matrix(C.byref(self.c)), "SparseFrame_read_matrix")
 
     def set_perm(self, perm):
+        """perm[new] = old; None = natural order (explicit opt-in: the default is the built-in nested dissection)"""
+        if perm is None:
+            check(self._lib.SparseFrame_set_perm(C.byref(self.c), None), "SparseFrame_set_perm")
+            return
         perm = _i64(perm)
         check(self._lib.SparseFrame_set_perm(C.byref(self.c), _lp(perm)), "SparseFrame_set_perm")
 
     def use_builtin_ordering(self):
-        """permMethod = PERM_METIS with no Perm supplied: SparseFrame_analyze orders with the built-in nested dissection"""
+        """permMethod = PERM_METIS with no Perm supplied (the default after initialize_matrix): SparseFrame_analyze orders
+        with the built-in nested dissection"""
         self.c.permMethod = 2
 
     def analyze(self, common):

@@ -48,6 +48,7 @@ struct Launch {
     uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
     double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
     bool split = false;         // distributed top: every rank executes 1/nranks of this launch's units
+    int ticket = 0;             // k_step launches: index of the launch's task-claim counter (d_info[1 + ticket])
 };
 
 // Distributed top phase (sf_chol_plan_create_distributed): phase 1 is cut into segments.  Before a segment runs, the
@@ -115,7 +116,7 @@ struct sf_chol_plan {
     int device = 0;
     int64_t n = 0, nsuper = 0, nnz = 0, isize = 0, xsize = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
 
     // device copies of the structure
     int64_t* d_Lp = nullptr;
@@ -127,7 +128,8 @@ struct sf_chol_plan {
     int32_t* d_Lsi = nullptr;
     int64_t* d_Lsxp = nullptr;
     double* d_Lsx = nullptr;
-    int* d_info = nullptr;
+    int* d_info = nullptr;      // [0]: status bits of the running factorization; [1 ..]: task-claim counters of the k_step launches
+    int n_tickets = 0;
 
     PotrfTask* d_potrf = nullptr;
     TrsmTask* d_trsm = nullptr;
@@ -196,6 +198,8 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->ev_s0) (void)hipEventDestroy(p->ev_s0);
+    if (p->ev_s1) (void)hipEventDestroy(p->ev_s1);
     if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return SF_OK;
@@ -284,6 +288,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
     }
     if (Super[0] != 0 || Super[nsuper] != n) { delete p; return SF_ERR_ARG; }
+    // SuperMap indexes level[] / phase[] below: it must be the inverse of Super (foreign arrays: checked, not trusted)
+    for (sf_long s = 0; s < nsuper; ++s)
+        for (sf_long j = Super[s]; j < Super[s + 1]; ++j)
+            if (SuperMap[j] != s) { delete p; return SF_ERR_ARG; }
 
     // ---------------- levels of the supernodal tree ----------------
     std::vector<int> level(nsuper, 0);
@@ -350,7 +358,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // Measured: 128^3 608 ms at 2048, 603 at 8192, 600 at 16384, 602 unlimited; 2-D 1000^2 (config 3) 12.0 ms up to 16384,
     // 12.3 at 32768, 13.3 unlimited
     // (LU config 5: 91.7 ms at 2048, 91.2 at 16384)
-    const int64_t fuse_max = 32 * sf::GEMM_GRID;
+    // SF_FUSE_MAX (debug knob, read at plan creation): 0 forces the three-launch form everywhere, so that both forms
+    // stay covered by the tests
+    int64_t fuse_max = 32 * sf::GEMM_GRID;
+    if (const char* env = getenv("SF_FUSE_MAX")) fuse_max = strtoll(env, nullptr, 10);
     for (int ph = 0; ph < 2; ++ph) {
     if (ph == 1) p->launch_split = p->launches.size();
     std::vector<std::vector<sf_long>> by_level(nlevels);
@@ -463,7 +474,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                             }
                         }
                     }
-                    if ((int64_t)steps.size() > d0) p->launches.push_back(Launch{5, d0, (int)(steps.size() - d0)});
+                    if ((int64_t)steps.size() > d0) {
+                        p->launches.push_back(Launch{5, d0, (int)(steps.size() - d0)});
+                        p->launches.back().ticket = p->n_tickets++;
+                    }
                     max_diag_tasks = std::max<int64_t>(max_diag_tasks, (int64_t)slot_of.size());
                     continue;
                 }
@@ -652,7 +666,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     int rc = SF_OK;
     do {
         if (hipStreamCreate(&p->stream) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess ||
-            hipEventCreate(&p->ev1) != hipSuccess) { rc = SF_ERR_HIP; break; }
+            hipEventCreate(&p->ev1) != hipSuccess || hipEventCreate(&p->ev_s0) != hipSuccess ||
+            hipEventCreate(&p->ev_s1) != hipSuccess) { rc = SF_ERR_HIP; break; }
         if ((rc = upload(&p->d_Lp, Lp64, &p->bytes_device))) break;
         if ((rc = upload(&p->d_Li, Li32, &p->bytes_device))) break;
         if ((rc = upload(&p->d_Super, Super32, &p->bytes_device))) break;
@@ -720,8 +735,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         // + 2 doubles: the GEMM stages row PAIRS with 16-byte loads and may touch 8 bytes past the last panel
         const size_t xb = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
-            hipMalloc((void**)&p->d_info, sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
-        p->bytes_device += xb + vb + sizeof(int);
+            hipMalloc((void**)&p->d_info, (1 + p->n_tickets) * sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+        p->bytes_device += xb + vb + (1 + p->n_tickets) * sizeof(int);
     } while (0);
     if (rc) { sf_chol_plan_destroy(p); return rc; }
     *out = p;
@@ -803,7 +818,11 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
     if (!p->values_set) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
-    std::vector<hipEvent_t> evs;
+    struct EventList {      // profiling events; destroyed on every exit path
+        std::vector<hipEvent_t> v;
+        ~EventList() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
+    } evlist;
+    std::vector<hipEvent_t>& evs = evlist.v;
     auto mark = [&]() {
         if (!p->profiling) return;
         hipEvent_t e;
@@ -815,7 +834,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         p->epoch = (p->epoch == 0x7fffffff) ? 1 : p->epoch + 1;     // flag value of this factorization's fused steps (never 0)
     }
     if (first) {
-        HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(p->d_info, 0, (1 + p->n_tickets) * sizeof(int), st));
         if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
         const int64_t* xp = (p->lu || p->partial) ? p->d_Xp : p->d_Lsxp;
         if (!p->lu) {
@@ -850,7 +869,10 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 sf::launch_update_small(p->d_probs, p->d_stasks + L.first + lo, (int)(hi - lo), p->d_Lsx, p->d_relmap, st);
                 break;
             }
-            case 5: sf::launch_step(p->d_steps + L.first, L.count, p->lu ? 1 : 0, p->d_Lsx, p->d_flags, p->epoch, p->d_info, p->d_tinv, st); break;
+            case 5:
+                sf::launch_step(p->d_steps + L.first, L.count, p->lu ? 1 : 0, p->d_Lsx, p->d_flags, p->epoch, p->d_info, p->d_tinv,
+                                p->d_info + 1 + L.ticket, st);
+                break;
             case 2:
             case 3:
             case 4: {
@@ -889,7 +911,6 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             }
         }
         if (dump) fclose(dump);
-        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     }
     if (sync) {
         if (!last) { HIP_TRY(hipStreamSynchronize(st)); return SF_OK; }
@@ -1075,8 +1096,9 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     hipStream_t st = p->stream;
     if (p->n <= 0) return SF_OK;
     HIP_TRY(hipMemcpyAsync(p->d_x, b_host, p->n * sizeof(double), hipMemcpyHostToDevice, st));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    // the plan's own event pair (ev0/ev1 time the factorization; sf_chol_plan_sync has read them by now): nothing is
+    // created here, so an error return leaks nothing
+    hipEvent_t e0 = p->ev_s0, e1 = p->ev_s1;
     HIP_TRY(hipEventRecord(e0, st));
     for (const auto& s : p->solve_steps) {
         sf::launch_solve_fwd_diag(p->d_solve + s.diag_first, s.diag_count, fwd_base, p->d_x, st, p->lu ? 1 : 0);
@@ -1093,7 +1115,6 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) p->last_solve_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return SF_OK;
 }
 

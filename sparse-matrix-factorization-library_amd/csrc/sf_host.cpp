@@ -201,7 +201,9 @@ int SparseFrame_initialize_matrix(struct matrix_info_struct* mi) {  // C:589-650
     mi->serial = serial;
     mi->path = path;
     mi->factorizeType = TYPE_CHOLESKY;
-    mi->permMethod = PERM_IDENTITY;
+    // the reference's analyze always orders with METIS (C:1937); here PERM_METIS with no Perm supplied selects the
+    // built-in nested dissection, and natural order is an explicit opt-in: SparseFrame_set_perm(mi, NULL)
+    mi->permMethod = PERM_METIS;
     return 0;
 }
 

@@ -86,11 +86,13 @@ void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shi
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
                     const double* PL, const double* PU, double* out, int64_t ref_size, hipStream_t st);
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
-// tasks: the diagonal blocks first, then the 64-row tiles below them; at most GEMM_GRID tasks (all resident at once);
+// tasks: the diagonal blocks first, then the 64-row tiles below them, any number (the grid need not be co-resident:
+// workgroups claim tasks in execution order through *ticket, which must be 0 at launch and is private to the launch);
 // flags[task.flag] == epoch once that diagonal block is factored
 // lu != 0: the diagonal tasks hold (L panel, U^T panel) and are factored without pivoting
 // tinv: scratch for the 16 x 16 inverses, 1024 (Cholesky) / 2048 (LU: of U11^T, then of L11) doubles per diagonal task of the launch
-void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, hipStream_t st);
+void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, int* ticket,
+                 hipStream_t st);
 // One-time (plan creation): relative maps of all scatter problems [first, first+count) -- the device form of the
 // reference's createRelativeMap (cuda_kernel.cu:42-60): RelMap[map_off + ci] = position of source row ci in the
 // target supernode's row list.

@@ -639,10 +639,10 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 // The row workgroups' update -- most of the step's work -- runs WHILE the diagonal block is being factored; they
 // pick the factored block up through a per-(panel, step) flag (release fence + relaxed store by the diagonal
 // workgroup, relaxed polls + one acquire fence by the waiting one, device scope; the flag value is the
-// factorization's epoch, so flags are never reset).  Liveness: diagonal workgroups never wait and have the lowest
-// block indices, so on every XCD (each dispatches its share of the grid in index order) they are placed before any
-// row workgroup of that XCD -- a waiting workgroup cannot keep the one it waits for off the chip, whatever the
-// grid size.  The wait is bounded all the same (info |= 2 -> SF_ERR_HIP instead of a hang).
+// factorization's epoch, so flags are never reset).  Liveness: tasks are handed out by an atomic ticket in the order
+// the workgroups actually start, and the diagonal tasks (which never wait) come first in the list -- see the top of
+// the kernel.  No assumption about the dispatch order or about co-residency of the grid is made.  The wait is
+// bounded all the same (info |= 2 -> SF_ERR_HIP instead of a hang).
 // Every element of the block column is read and written once.  4 waves (2 x 2), each a 32 x 32 sub-tile = 2 x 2
 // v_mfma_f64_16x16x4_f64 tiles; K is short (<= 448), so the MFMA fragments are loaded straight from the panel
 // (16 consecutive rows x 4 k per load), 32 k ahead in registers, no LDS staging and no barriers in the K loop.
@@ -656,7 +656,7 @@ constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 template <bool LU>
 __global__ void __launch_bounds__(256, LU ? 2 : 3)   // LU: the unblocked GETRF keeps a 64-value row per lane
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info,
-       double* __restrict__ tinv) {
+       double* __restrict__ tinv, int* __restrict__ ticket) {
     // ONE LDS array, re-used by the phases of a task:
     //   update:            X staging buffers Xs[2][32][80]
     //   diagonal task:     U[c][r], the updated block (POTRF / GETRF works on it)
@@ -668,9 +668,16 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     double* __restrict__ U = smem;
     double (*Dt)[NB] = reinterpret_cast<double (*)[NB]>(smem);
 
-    const StepTask t = tasks[blockIdx.x];
-    const bool is_diag = t.row0 == t.diag;
+    // Tasks are claimed in EXECUTION order (one atomic ticket per workgroup), not by blockIdx: the diagonal tasks come
+    // first in the list, so every one of them is held by a workgroup that is already running -- and never waits -- by
+    // the time any row task is claimed.  A waiting workgroup can therefore never keep the one it waits for off the
+    // chip, whatever order the hardware dispatches the grid in and whatever else shares the GPU.
+    __shared__ int s_ticket;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const StepTask t = tasks[__builtin_amdgcn_readfirstlane(s_ticket)];
+    const bool is_diag = t.row0 == t.diag;
     const int fr = lane & 15, fk = lane >> 4;
     const int64_t ld = t.ld;
     const int b = t.b, nrows = t.nrows;
@@ -996,10 +1003,11 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     }
 }
 
-void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, hipStream_t st) {
+void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, int* ticket,
+                 hipStream_t st) {
     if (ntasks <= 0) return;
-    if (lu) hipLaunchKernelGGL(k_step<true>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv);
-    else hipLaunchKernelGGL(k_step<false>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv);
+    if (lu) hipLaunchKernelGGL(k_step<true>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv, ticket);
+    else hipLaunchKernelGGL(k_step<false>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------------

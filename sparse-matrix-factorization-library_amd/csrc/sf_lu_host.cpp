@@ -103,7 +103,8 @@ int SparseFrame_initialize_matrix(struct matrix_info_struct* mi) {   // L:675-74
     mi->serial = serial;
     mi->path = path;
     mi->factorizeType = TYPE_LU;
-    mi->permMethod = PERM_IDENTITY;
+    // as the Cholesky library: ordered by default (the reference always calls METIS, L:2271), identity by opt-in
+    mi->permMethod = PERM_METIS;
     return 0;
 }
 
@@ -197,6 +198,13 @@ int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_st
     const double t0 = wall_seconds();
     sf_symbolic* S = nullptr;
     const sf_long* perm = (mi->permMethod != PERM_IDENTITY) ? mi->Perm : nullptr;
+    std::vector<sf_long> builtin;
+    if (mi->permMethod != PERM_IDENTITY && !mi->Perm) {
+        // built-in nested dissection of the pattern of A + A^T (stands in for METIS_NodeND, L:2271)
+        builtin.resize(mi->nrow > 0 ? mi->nrow : 1);
+        if (sf_graph_nd_perm(mi->nrow, mi->Cp, mi->Ci, 64, builtin.data())) return 1;
+        perm = builtin.data();
+    }
     if (sf_symbolic_create_lu(&S, mi->nrow, mi->Cp, mi->Ci, mi->Cx, perm, common->devSlotSize, mi->isSymmetric)) return 1;
 
     SF_FREE(Lp); SF_FREE(Li); SF_FREE(Lx); SF_FREE(LTp); SF_FREE(LTi); SF_FREE(LTx);

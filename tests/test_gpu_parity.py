@@ -86,6 +86,7 @@ def test_struct_entry_points_end_to_end(oracle, tmp_path):
     common.c.devSlotSize = 1 << 30
     mi = sf.MatrixInfo()
     mi.read(path)
+    mi.set_perm(None)            # config 1 is quoted in natural order (explicit opt-in; the default orders)
     mi.analyze(common)
     assert (mi.c.nsuper, mi.c.nstage) == (155, 1)
     mi.factorize(common)
@@ -360,3 +361,43 @@ def test_device_solve_residual_48cubed(oracle):
     assert res <= TOL_RESIDUAL
     assert plan.stat("last_solve_ms") > 0
     plan.close()
+
+
+def test_three_launch_form_forced(oracle, monkeypatch):
+    """SF_FUSE_MAX=0 (read at plan creation) turns every fused k_step launch into its three-launch form -- stream-K GEMM,
+    one-wave POTRF, TRSM workgroups -- so that both forms stay covered; same factor either way"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(14, 14, 14)
+    sym = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(14, 14, 14), 8 << 30)
+    assert np.diff(sym.Super).max() > 128
+    ref, info, _ = oracle.chol_factorize(sym)
+    mask = oracle.lower_mask(sym)
+    plan, fused = gpu_factor(sym)
+    n_fused = plan.stat("launches")
+    plan.close()
+    monkeypatch.setenv("SF_FUSE_MAX", "0")
+    plan, three = gpu_factor(sym)
+    assert plan.stat("launches") > n_fused
+    plan.close()
+    assert rel_err(fused, ref, mask) <= TOL_FACTOR and rel_err(three, ref, mask) <= TOL_FACTOR
+
+
+def test_two_plans_concurrently_on_one_gpu(oracle):
+    """the flag hand-off of k_step under contention: two plans (two streams) factorize at the same time on one GPU, each
+    with fused steps of more workgroups than fit the chip next to the other's.  Tasks are claimed by ticket in execution
+    order, so no wait can starve its producer; SF_ERR_HIP (info bit 2: a bounded wait ran out) would fail the check."""
+    n, Cp, Ci, Cx = gen.laplacian_lower(40, 40, 40)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(40, 40, 40), 8 << 30)
+    plans = [sf.CholPlan(sym, device=0) for _ in range(2)]
+    for k, p in enumerate(plans):
+        p.set_values(sym.Lx * (1.0 + k))
+    for _ in range(3):
+        for p in plans:
+            p.factorize(sync=False)
+    for p in plans:
+        p.sync()                                   # raises SparseFrameError on SF_ERR_HIP / SF_ERR_NOT_POSDEF
+    ref, info, _ = oracle.chol_factorize(sym)
+    mask = oracle.lower_mask(sym)
+    for k, p in enumerate(plans):
+        Lsx = p.get_factor()
+        assert rel_err(Lsx, ref * np.sqrt(1.0 + k), mask) <= TOL_FACTOR
+        p.close()

@@ -1,5 +1,6 @@
 """The oracle against everything that pins it:
- (a) counts of real reference runs recorded by the survey session,
+ (a) survey-recorded counts: printed by a survey-time build against stand-in headers, which by the
+     rules pins nothing -- a consistency check with the survey's numbers only; parity with the actual reference is UNPINNED,
  (b) brute-force definitions of the symbolic quantities,
  (c) dense LAPACK Cholesky (the factor is unique), for both BLAS back ends of the oracle."""
 import json
@@ -30,7 +31,8 @@ def brute_symbolic(n, Lp, Li):
     return parent, [len(c) + 1 for c in cols], cols
 
 
-def test_recorded_reference_run_2d(oracle):
+def test_survey_recorded_counts_2d(oracle):
+    """survey-recorded, stub-header build; parity unpinned"""
     rec = RECORDED["lap2d_100x100_identity_1GiB"]
     n, Cp, Ci, Cx = gen.laplacian_lower(100, 100)
     assert len(Ci) == rec["mtx_entries"]
@@ -38,7 +40,8 @@ def test_recorded_reference_run_2d(oracle):
     assert (S["nfsuper"], S["nsuper"], S["nstage"]) == (rec["nfsuper"], rec["nsuper"], rec["nstage"])
 
 
-def test_recorded_reference_run_3d_32(oracle):
+def test_survey_recorded_counts_3d_32(oracle):
+    """survey-recorded, stub-header build; parity unpinned"""
     rec = RECORDED["lap3d_32_geomND_8GiB"]
     n, Cp, Ci, Cx = gen.laplacian_lower(32, 32, 32)
     S = oracle.symbolic.analyze(n, Cp, Ci, Cx, nd_perm_py(32, 32, 32), 8 << 30)

@@ -40,7 +40,7 @@ def test_analyze_uses_builtin_ordering_when_none_is_supplied(oracle):
     common = sf.CommonInfo(dev_slot_size=1 << 30)
     mi = sf.MatrixInfo()
     mi.set_csc(n, Cp, Ci, Cx)
-    mi.use_builtin_ordering()
+    assert mi.c.permMethod == 2      # the default after initialize_matrix: ordered, as the reference (C:1937)
     mi.analyze(common)
     perm = mi.array("Perm", n).copy()
     assert sorted(perm.tolist()) == list(range(n))
@@ -52,4 +52,26 @@ def test_analyze_uses_builtin_ordering_when_none_is_supplied(oracle):
     Lsx, info, _ = oracle.chol_factorize(S)
     res, _ = oracle.chol_residual(S, Lsx)
     assert info == 0 and res <= 1e-13
+    mi.cleanup()
+
+
+def test_default_ordering_fill_is_close_to_geometric_nested_dissection():
+    """reference call order (initialize, set matrix, analyze) with no ordering supplied must not factorize a 3-D problem in
+    natural order: the built-in ordering's fill stays within 2x of the geometric nested dissection's, natural order is
+    several times worse; set_perm(None) is the explicit natural-order opt-in"""
+    N = 16
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    mi = sf.MatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx)
+    mi.analyze(common)
+    geo = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 1 << 30)
+    ident = sf.analyze(n, Cp, Ci, Cx, None, 1 << 30)
+    fill_default = int(np.sum(mi.array("ColCount", n)))
+    fill_geo, fill_ident = int(np.sum(geo.ColCount)), int(np.sum(ident.ColCount))
+    assert fill_default <= 2.0 * fill_geo, (fill_default, fill_geo)
+    assert fill_ident >= 2.0 * fill_default, (fill_ident, fill_default)
+    mi.set_perm(None)
+    mi.analyze(common)
+    assert int(np.sum(mi.array("ColCount", n))) == fill_ident
     mi.cleanup()

@@ -36,6 +36,8 @@ int main() {
     CK(hipMemset(flags, 0, sizeof(int)));
     double* tinv;
     CK(hipMalloc(&tinv, 1024 * sizeof(double)));
+    int* tickets;            // one task-claim counter per launch (reps + 1 launches per configuration)
+    CK(hipMalloc(&tickets, 64 * sizeof(int)));
     int epoch = 0;
     printf("row-tiles ti   us/launch   (one diagonal workgroup + row tiles, one k_step launch)\n");
     for (int ntiles : {0, 1, 64, 207, 414, 511}) {
@@ -46,10 +48,11 @@ int main() {
             for (int k = 0; k < ntiles; ++k) t.push_back(sf::StepTask{0, 0, (int32_t)nsrow, 0, diag, 64, 512 + 64 * k, 64, 0, 0, 0, 0});
             CK(hipMemcpy(dt, t.data(), t.size() * sizeof(sf::StepTask), hipMemcpyHostToDevice));
             const int reps = 20;
-            sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, 0);
+            CK(hipMemset(tickets, 0, 64 * sizeof(int)));
+            sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, tickets + reps, 0);
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
-            for (int r = 0; r < reps; ++r) sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, 0);
+            for (int r = 0; r < reps; ++r) sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, tickets + r, 0);
             CK(hipEventRecord(e1, 0));
             CK(hipDeviceSynchronize());
             float ms;
