@@ -53,9 +53,10 @@ def main():
                     help="N > 1 with --mp subtree*: weak = grid round(base * N^(1/6)) (flops per GPU fixed), strong = base grid")
     ap.add_argument("--check", action="store_true", help="download the factor and check the residual on the host")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--pcie", action="store_true",
-                    help="N = 1: also time the host-buffer boundary (values H2D + factorize + factor D2H, what the struct "
-                         "entry point SparseFrame_factorize does per call) and report it in config.pcie_inclusive; never `value`")
+    ap.add_argument("--no-pcie", action="store_true",
+                    help="N = 1: skip the host-buffer boundary lines (values H2D + factorize + overlapped factor D2H at plan level and "
+                         "through the struct entry point SparseFrame_factorize), reported in config.pcie_inclusive; never `value`")
+    ap.add_argument("--pcie", action="store_true", help="(default now; kept for compatibility)")
     args = ap.parse_args()
 
     import numpy as np
@@ -96,17 +97,26 @@ def main():
         N = int(round(N * world ** (1.0 / 6.0)))      # F ~ g^6: the flops per GPU stay those of the base grid
     t0 = time.time()
 
-    def make(M):
+    inputs = {}
+
+    def make(M, keep=False):
         if lu:   # BASELINE config 5 stand-in: n ~ 500k, nnz ~ 9M, structurally and numerically unsymmetric, diagonally dominant
             n_, Cp_, Ci_, Cx_ = sf.gen.unsymmetric_stencil(M, M, M, extra_per_row=0, seed=2024, drop=0.05)
-            return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False), len(Ci_)
-        if args.workload == "stencil2d":
+            perm_ = sf.grid_nd_perm(M, M, M, 3, 1)
+            sym_ = sf.analyze(n_, Cp_, Ci_, Cx_, perm_, sf.REFERENCE_SLOT_1GPU, "lu", False)
+        elif args.workload == "stencil2d":
             n_, Cp_, Ci_, Cx_ = sf.gen.stencil_spd_lower(M, M)
-            return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, 1, 3, 2), sf.REFERENCE_SLOT_1GPU), len(Ci_)
-        n_, Cp_, Ci_, Cx_ = sf.gen.laplacian_lower(M, M, M)
-        return n_, sf.analyze(n_, Cp_, Ci_, Cx_, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU), len(Ci_)
+            perm_ = sf.grid_nd_perm(M, M, 1, 3, 2)
+            sym_ = sf.analyze(n_, Cp_, Ci_, Cx_, perm_, sf.REFERENCE_SLOT_1GPU)
+        else:
+            n_, Cp_, Ci_, Cx_ = sf.gen.laplacian_lower(M, M, M)
+            perm_ = sf.grid_nd_perm(M, M, M, 3, 1)
+            sym_ = sf.analyze(n_, Cp_, Ci_, Cx_, perm_, sf.REFERENCE_SLOT_1GPU)
+        if keep:
+            inputs.update(n=n_, Cp=Cp_, Ci=Ci_, Cx=Cx_, perm=perm_)
+        return n_, sym_, len(Ci_)
 
-    n, sym, nnz_in = make(N)
+    n, sym, nnz_in = make(N, keep=True)
     t_analyze = time.time() - t0
     F_struct, F_exec = sym.flops_struct, sym.flops_exec
 
@@ -222,24 +232,45 @@ def main():
         out["config"]["residual_device_solve"] = sf.validate_solution(sym, xs)
         out["config"]["device_solve_ms"] = round(plan.stat("last_solve_ms"), 3)
 
-    if args.pcie and rank == 0 and sharded is None:
-        host = np.empty(max(sym.xsize, 1), dtype=np.float64)
-        host[:] = 0.0                                    # touch the pages: first-touch faults are not PCIe time
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    if rank == 0 and sharded is None and not args.no_pcie:
+        # Host-buffer boundary (never `value`): what the drop-in entry point costs.
+        #  (a) plan level: values H2D + factorize + factor D2H into pageable memory, the download of finished blocks
+        #      overlapped with the computation (sf_chol_plan_factorize_to_host); first call = fresh, never touched pages
+        #  (b) the reference's own entry point SparseFrame_factorize over matrix_info_struct, twice on one handler list:
+        #      the first call also builds and caches the device plan, the second finds it
+        def timed(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            return (time.perf_counter() - t0) * 1e3
+
+        host = np.empty(max(sym.xsize, 1), dtype=np.float64)      # untouched pages: the first call pays the first touch
         if lu:
-            plan.set_values(sym.Lx, sym.Ux)
+            ms = [timed(lambda: plan.factorize_to_host(sym.Lx, sym.Ux, host)) for _ in range(2)]
         else:
-            plan.set_values(sym.Lx)
-        plan.factorize(sync=True)
-        t1 = time.perf_counter()
-        plan.get_factor(host)
-        t2 = time.perf_counter()
-        out["config"]["pcie_inclusive"] = {"ms": round((t2 - t0) * 1e3, 1), "factor_download_ms": round((t2 - t1) * 1e3, 1),
-                                           "factor_bytes": int(sym.xsize) * 8,
-                                           "GFLOPs": round(F_struct / (t2 - t0) / 1e9, 1),
-                                           "note": "pageable host memory; upload of the values + factorize + download of the factor"}
+            ms = [timed(lambda: plan.factorize_to_host(sym.Lx, host)) for _ in range(2)]
         del host
+        pc = {"plan_first_call_ms": round(ms[0], 1), "plan_second_call_ms": round(ms[1], 1),
+              "factor_bytes": int(sym.xsize) * 8,
+              "second_call_over_resident_step": round(ms[1] / ms_per_step, 3),
+              "GFLOPs_second_call": round(F_struct / (ms[1] * 1e-3) / 1e9, 1)}
+        common = sf.CommonInfo(dev_slot_size=sf.REFERENCE_SLOT_1GPU)
+        mi = (sf.LUMatrixInfo if lu else sf.MatrixInfo)()
+        mi.set_csc(inputs["n"], inputs["Cp"], inputs["Ci"], inputs["Cx"], symmetric=not lu)
+        mi.set_perm(inputs["perm"])
+        mi.analyze(common)
+        st = []
+        for _ in range(2):
+            mi.factorize(common)
+            st.append(mi.c.factorizeTime * 1e3)
+        pc.update({"struct_first_call_ms": round(st[0], 1), "struct_second_call_ms": round(st[1], 1),
+                   "struct_second_call_over_resident_step": round(st[1] / ms_per_step, 3),
+                   "struct_residual": mi.validate() if n <= 300000 else None,
+                   "note": "SparseFrame_factorize(common, gpu_info_list, matrix_info): pageable Lsx malloc'ed by SparseFrame_analyze; "
+                           "call 1 = plan build + first touch of Lsx + factorize + overlapped copy-back, call 2 = cached plan"})
+        mi.cleanup()
+        common.close()
+        out["config"]["pcie_inclusive"] = pc
 
     if args.check and sharded is not None:
         import oracle

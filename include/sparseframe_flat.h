@@ -111,6 +111,11 @@ int sf_chol_plan_factorize(sf_chol_plan *plan, int sync);
 int sf_chol_plan_sync(sf_chol_plan *plan);
 /* D2H copy of the factor into the reference layout (xsize doubles). */
 int sf_chol_plan_get_factor(sf_chol_plan *plan, sf_float *Lsx);
+/* values H2D + numeric factorization + factor D2H into host_out (reference layout, xsize doubles), the download of
+ * finished blocks overlapped with the computation of the levels above them (the reference's copy-back stream,
+ * C:2888-2895).  host_out may be ordinary pageable memory (it is never pinned or registered).  Ux: LU plans only (NULL
+ * when U aliases L).  "last_to_host_ms" reports the wall time of the call. */
+int sf_chol_plan_factorize_to_host(sf_chol_plan *plan, const sf_float *Lx, const sf_float *Ux, sf_float *host_out);
 /* device pointer of the resident factor (for device-side consumers) */
 void *sf_chol_plan_factor_device_ptr(sf_chol_plan *plan);
 /* device-side supernodal solve with the resident factor: x <- (L L^T)^{-1} b, permuted space */
@@ -202,6 +207,18 @@ int sf_lu_plan_solve(sf_lu_plan *plan, const sf_float *b_host, sf_float *x_host)
 double sf_lu_plan_stat(const sf_lu_plan *plan, const char *name);
 int sf_lu_plan_set_profiling(sf_lu_plan *plan, int on);
 int sf_lu_plan_destroy(sf_lu_plan *plan);
+
+/* ---- device handlers: what SparseFrame_allocate_gpu / _free_gpu / _factorize_supernodal of BOTH struct libraries
+ * forward to (reference C:16-366, C:2150-3017).  A handler keeps a lock and a cache of device plans keyed by the
+ * symbolic pattern, so repeated factorizations of one pattern pay for the plan once.  lu != 0: LU arrays (Up/Ui/Ux
+ * NULL when U aliases L).  serial selects the handler (matrix threads spread over the devices). ---- */
+int sf_handlers_allocate(struct common_info_struct *common_info, struct gpu_info_struct **gpu_info_list_ptr);
+int sf_handlers_free(struct common_info_struct *common_info, struct gpu_info_struct **gpu_info_list_ptr);
+int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_info_struct *gpu_info_list, int lu, int serial,
+                          sf_long n, sf_long nsuper, const sf_long *Super, const sf_long *SuperMap,
+                          const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                          const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
+                          const sf_float *Lx, const sf_float *Ux, sf_float *Lsx_out);
 
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
 int sf_device_count(void);

@@ -78,6 +78,8 @@ lib.sf_chol_plan_sync.argtypes = [C.c_void_p]
 lib.sf_chol_plan_sync.restype = C.c_int
 lib.sf_chol_plan_get_factor.argtypes = [C.c_void_p, c_double_p]
 lib.sf_chol_plan_get_factor.restype = C.c_int
+lib.sf_chol_plan_factorize_to_host.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
+lib.sf_chol_plan_factorize_to_host.restype = C.c_int
 lib.sf_chol_plan_factor_device_ptr.argtypes = [C.c_void_p]
 lib.sf_chol_plan_factor_device_ptr.restype = C.c_void_p
 lib.sf_chol_plan_solve.argtypes = [C.c_void_p, c_double_p, c_double_p]

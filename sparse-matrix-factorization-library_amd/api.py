@@ -261,6 +261,15 @@ class CholPlan(_ShardedPlanMixin):
         check(lib.sf_chol_plan_get_factor(self._h, _dp(out)), "sf_chol_plan_get_factor")
         return out[:self.xsize]
 
+    def factorize_to_host(self, Lx, out=None):
+        """values H2D + factorize + factor D2H into `out` (pageable numpy memory), the download overlapped with the
+        computation -- what one SparseFrame_factorize call does once its plan exists"""
+        Lx = _f64(Lx)
+        if out is None:
+            out = np.empty(max(self.xsize, 1), dtype=np.float64)
+        check(lib.sf_chol_plan_factorize_to_host(self._h, _dp(Lx), None, _dp(out)), "sf_chol_plan_factorize_to_host")
+        return out[:self.xsize]
+
     def solve(self, b):
         b = _f64(b)
         x = np.empty_like(b)
@@ -326,6 +335,15 @@ class LUPlan(_ShardedPlanMixin):
         if out is None:
             out = np.empty(max(self.xsize, 1), dtype=np.float64)
         check(lib.sf_lu_plan_get_factor(self._h, _dp(out)), "sf_lu_plan_get_factor")
+        return out[:self.xsize]
+
+    def factorize_to_host(self, Lx, Ux=None, out=None):
+        """as CholPlan.factorize_to_host; the factor arrives in the reference's packed LU layout"""
+        Lx = _f64(Lx)
+        if out is None:
+            out = np.empty(max(self.xsize, 1), dtype=np.float64)
+        ux = None if self._alias else _dp(_f64(Ux))
+        check(lib.sf_chol_plan_factorize_to_host(self._h, _dp(Lx), ux, _dp(out)), "sf_chol_plan_factorize_to_host")
         return out[:self.xsize]
 
     def solve(self, b):

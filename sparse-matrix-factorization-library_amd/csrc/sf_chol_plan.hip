@@ -28,139 +28,7 @@
 #include <string>
 #include <vector>
 
-#include "sf_kernels.h"
-
-using sf::GemmProb;
-using sf::GemmTask;
-using sf::PotrfTask;
-using sf::TrsmTask;
-using sf::StepTask;
-
-namespace {
-
-struct Launch {
-    int kind;       // 0 potrf, 1 trsm, 2 gemm panel (inner, K = NB), 3 gemm scatter, 4 gemm panel (outer, large K),
-                    // 6 Schur updates with K <= SU_MAXK (k_update_small, tasks in stasks),
-                    // 5 fused step k_step (Cholesky, steps of at most GEMM_GRID workgroups; otherwise and for LU: 2, 0, 1)
-    int64_t first;  // first task
-    int count;
-    int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
-    uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
-    double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
-    bool split = false;         // distributed top: every rank executes 1/nranks of this launch's units
-    int ticket = 0;             // k_step launches: index of the launch's task-claim counter (d_info[1 + ticket])
-};
-
-// Distributed top phase (sf_chol_plan_create_distributed): phase 1 is cut into segments.  Before a segment runs, the
-// regions it lists (the 512-column block of every top panel of the level whose 64-column chain is about to start) are
-// summed over the ranks; until then a block only ever received additive updates (subtree Schur updates, split top
-// Schur updates, split outer GEMMs), so its true value is the sum of the ranks' copies.
-struct Segment {
-    size_t l0 = 0, l1 = 0;                 // launches [l0, l1)
-    std::vector<int64_t> off, cnt;         // whole block columns: doubles, relative to the factor base pointer
-    // the part of each region that can be non-zero (rows >= the block's first column): `cols` pieces of `rows` doubles,
-    // `ld` apart, starting at `src` -- what sf_chol_plan_segment_pack gathers into one contiguous buffer
-    std::vector<int64_t> src, rows, cols, ld;
-    int64_t packed = 0;                    // doubles in the packed buffer
-};
-
-#define HIP_TRY(expr)                                                                       \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess) {                                                             \
-            fprintf(stderr, "[sparseframe-hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return SF_ERR_HIP;                                                              \
-        }                                                                                   \
-    } while (0)
-
-template <class T>
-int upload(T** dptr, const std::vector<T>& h, size_t* bytes_total) {
-    *dptr = nullptr;
-    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
-    HIP_TRY(hipMalloc((void**)dptr, bytes));
-    if (!h.empty()) HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    *bytes_total += bytes;
-    return SF_OK;
-}
-
-}  // namespace
-
-struct sf_chol_plan {
-    bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
-    int64_t xC = 0;             // doubles in one set of nsrow x nscol panels (Cholesky: == xsize)
-    int64_t unz = 0;            // LU: entries of U (by row)
-    int64_t* d_Up = nullptr;    // LU, unsymmetric input: U by row
-    int32_t* d_Ui = nullptr;
-    double* d_Ux = nullptr;
-    int64_t* d_Xp = nullptr;    // LU: offsets of the nsrow x nscol panels (the reference's Lsxp has the packed sizes)
-    double* d_pack = nullptr;   // LU: staging buffer in the reference layout for the download
-    bool u_alias = false;       // LU with a symmetric input: U aliases L (reference L:2718-2729)
-    // multi-GPU sharding: phase[s] = 0 owned subtree supernode, 1 top supernode (replicated), -1 not on this rank
-    std::vector<int8_t> phase;
-    std::vector<int64_t> h_XP;  // device panel offsets (doubles), -1 when the panel is not stored on this rank
-    bool partial = false;       // some supernodes are absent or the top panels are not loaded here
-    int64_t top_off = 0, top_size = 0;   // contiguous region of the top panels inside one panel set
-    size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
-    int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
-    std::vector<Segment> segments;
-    double* d_scratch = nullptr;   // packed segment buffer (max over the segments)
-    int64_t packed_pending = -1;   // segment whose packed buffer has to be scattered back before it runs
-    bool own_stream = true;
-    int8_t* d_loadmask = nullptr;
-    // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
-    sf::SolveTask* d_solve = nullptr;
-    double* d_x = nullptr;
-    struct SolveStep { int64_t diag_first; int diag_count; int64_t fwd_first; int fwd_count; int64_t bwd_first; int bwd_count; };
-    std::vector<SolveStep> solve_steps;
-    double last_solve_ms = 0;
-    int device = 0;
-    int64_t n = 0, nsuper = 0, nnz = 0, isize = 0, xsize = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
-
-    // device copies of the structure
-    int64_t* d_Lp = nullptr;
-    int32_t* d_Li = nullptr;
-    double* d_Lx = nullptr;
-    int32_t* d_Super = nullptr;
-    int32_t* d_SuperMap = nullptr;
-    int64_t* d_Lsip = nullptr;
-    int32_t* d_Lsi = nullptr;
-    int64_t* d_Lsxp = nullptr;
-    double* d_Lsx = nullptr;
-    int* d_info = nullptr;      // [0]: status bits of the running factorization; [1 ..]: task-claim counters of the k_step launches
-    int n_tickets = 0;
-
-    PotrfTask* d_potrf = nullptr;
-    TrsmTask* d_trsm = nullptr;
-    StepTask* d_steps = nullptr;
-    int* d_flags = nullptr;     // k_step: one flag per (panel, fused step); == epoch once its diagonal block is factored
-    double* d_tinv = nullptr;   // k_step: inverses of the 16 x 16 diagonal sub-blocks, per diagonal task of the running launch
-    int epoch = 0;
-    GemmProb* d_probs = nullptr;
-    GemmTask* d_gtasks = nullptr;
-    GemmTask* d_stasks = nullptr;   // tiles of k_update_small
-    uint32_t* d_ktprefix = nullptr;
-    int32_t* d_relmap = nullptr;
-
-    std::vector<Launch> launches;
-    int nlevels = 0;
-    int64_t n_gemm_tasks = 0, n_pairs = 0;
-    double flops_update_small = 0;      // part of flops_update done by k_update_small (K <= SU_MAXK)
-    double flops_exec = 0, flops_update = 0, scatter_elems = 0, flops_panel_gemm = 0, flops_outer_gemm = 0;
-    size_t bytes_device = 0;
-    bool values_set = false;
-
-    bool profiling = false;
-    double last_ms = 0, last_load_ms = 0, last_panel_ms = 0, last_update_ms = 0;
-    double last_kind_ms[7] = {0, 0, 0, 0, 0, 0, 0};
-    int last_status = SF_OK;
-
-    // host copies needed by the device solve
-    std::vector<int64_t> h_Lsip, h_Lsxp;
-    std::vector<int32_t> h_Super;
-    std::vector<int> level_of;
-};
+#include "sf_plan_internal.h"
 
 extern "C" {
 
@@ -200,6 +68,15 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->ev_s0) (void)hipEventDestroy(p->ev_s0);
     if (p->ev_s1) (void)hipEventDestroy(p->ev_s1);
+    for (hipEvent_t e : p->dl_events)
+        if (e) (void)hipEventDestroy(e);
+    for (int w = 0; w < DL_WORKERS; ++w) {
+        if (p->dl_streams[w]) (void)hipStreamDestroy(p->dl_streams[w]);
+        for (int k = 0; k < 2; ++k)
+            if (p->dl_done[w][k]) (void)hipEventDestroy(p->dl_done[w][k]);
+    }
+    if (p->h_ring) (void)hipHostFree(p->h_ring);
+    if (p->d_ring) (void)hipFree(p->d_ring);
     if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return SF_OK;
@@ -350,6 +227,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         gtasks.push_back(GemmTask{prob_id, (uint16_t)tm, (uint16_t)tn, (uint32_t)k0, (uint32_t)std::min(gemm_slice, nkt_all - k0)});
                     }
     };
+
+    // download schedule: launch count after which block column jo of supernode s is final (its 64-column chain is done)
+    std::vector<int64_t> blk_first(nsuper + 1, 0);
+    for (sf_long s = 0; s < nsuper; ++s) blk_first[s + 1] = blk_first[s] + (Super[s + 1] - Super[s] + sf::OUTER_NB - 1) / sf::OUTER_NB;
+    std::vector<size_t> blk_ready(blk_first[nsuper], 0);
 
     int32_t n_flags = 0;
     int64_t max_diag_tasks = 0;     // k_step launches: scratch for the 16 x 16 inverses, 1024 doubles per diagonal task
@@ -518,6 +400,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
                 if ((int64_t)trsm.size() > t0) p->launches.push_back(Launch{1, t0, (int)(trsm.size() - t0)});
             }
+            for (sf_long s : Sl)
+                if (J < Super[s + 1] - Super[s]) blk_ready[blk_first[s] + jo] = p->launches.size();
         }
         // Schur updates of every supernode of this level into its ancestors
         const int64_t g0 = (int64_t)gtasks.size(), s0 = (int64_t)stasks.size();
@@ -647,6 +531,47 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         L.units = (uint32_t)run;
     }
 
+    // ---------------- download schedule (sf_chol_plan_factorize_to_host) ----------------
+    // Block columns in host order, merged while contiguous in the host layout (Cholesky: and in the device layout) up to
+    // one staging slot, larger runs cut into slot-sized pieces.  Top panels of a sharded plan are identical on every
+    // rank once factored: their pieces are dealt out over the ranks so that every PCIe link carries a share.
+    {
+        std::vector<DlPiece> runs;
+        int last_phase = -2;
+        for (sf_long s = 0; s < nsuper; ++s) {
+            if (XP[s] < 0) continue;
+            const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+            const int64_t hld = lu ? 2 * nsrow - nscol : nsrow;
+            for (int64_t jo = 0; jo * sf::OUTER_NB < nscol; ++jo) {
+                const int64_t J = jo * sf::OUTER_NB, w = std::min<int64_t>(sf::OUTER_NB, nscol - J);
+                DlPiece pc{XP[s] + J * nsrow, Lsxp[s] + J * hld, w * hld, blk_ready[blk_first[s] + jo], 0};
+                const bool can_merge = !runs.empty() && last_phase == p->phase[s] &&
+                                       runs.back().host_off + runs.back().count == pc.host_off &&
+                                       (lu || runs.back().dev_off + runs.back().count == pc.dev_off) &&
+                                       runs.back().count + pc.count <= DL_SLOT;
+                if (can_merge) {
+                    runs.back().count += pc.count;
+                    runs.back().ready = std::max(runs.back().ready, pc.ready);
+                } else {
+                    pc.ev = p->phase[s];        // phase kept here until the pieces are dealt out below
+                    runs.push_back(pc);
+                }
+                last_phase = p->phase[s];
+            }
+        }
+        int64_t top_seen = 0;
+        for (const DlPiece& r : runs) {
+            if (r.ev == 1 && nranks > 1 && (top_seen++ % nranks) != rank) continue;
+            for (int64_t o = 0; o < r.count; o += DL_SLOT)
+                p->dl_pieces.push_back(DlPiece{r.dev_off + o, r.host_off + o, std::min(DL_SLOT, r.count - o), r.ready, 0});
+        }
+        std::stable_sort(p->dl_pieces.begin(), p->dl_pieces.end(), [](const DlPiece& a, const DlPiece& b) { return a.ready < b.ready; });
+        for (DlPiece& pc : p->dl_pieces) {
+            if (p->dl_ev_ready.empty() || p->dl_ev_ready.back() != pc.ready) p->dl_ev_ready.push_back(pc.ready);
+            pc.ev = (int)p->dl_ev_ready.size() - 1;
+        }
+    }
+
     // ---------------- upload ----------------
     std::vector<int32_t> Li32(p->nnz), Super32(nsuper + 1), SuperMap32(n), Lsi32(p->isize);
     for (sf_long k = 0; k < p->nnz; ++k) Li32[k] = (int32_t)Li[k];
@@ -668,6 +593,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (hipStreamCreate(&p->stream) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess ||
             hipEventCreate(&p->ev1) != hipSuccess || hipEventCreate(&p->ev_s0) != hipSuccess ||
             hipEventCreate(&p->ev_s1) != hipSuccess) { rc = SF_ERR_HIP; break; }
+        p->dl_events.assign(p->dl_ev_ready.size(), nullptr);
+        {
+            bool ok = true;
+            for (hipEvent_t& e : p->dl_events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { rc = SF_ERR_HIP; break; }
+        }
         if ((rc = upload(&p->d_Lp, Lp64, &p->bytes_device))) break;
         if ((rc = upload(&p->d_Li, Li32, &p->bytes_device))) break;
         if ((rc = upload(&p->d_Super, Super32, &p->bytes_device))) break;
@@ -813,6 +744,26 @@ int sf_chol_plan_sync(sf_chol_plan* p) {
     return p->last_status;
 }
 
+// overlapped download: record the events of everything that is final once `done` launches have been enqueued and
+// tell the copy workers about them
+static hipError_t dl_publish(sf_chol_plan* p, size_t done) {
+    size_t k = p->dl_next_ev;
+    while (k < p->dl_ev_ready.size() && p->dl_ev_ready[k] <= done) {
+        const hipError_t e = hipEventRecord(p->dl_events[k], p->stream);
+        if (e != hipSuccess) return e;
+        ++k;
+    }
+    if (k != p->dl_next_ev) {
+        p->dl_next_ev = k;
+        {
+            std::lock_guard<std::mutex> g(p->dl_mu);
+            p->dl_published = k;
+        }
+        p->dl_cv.notify_all();
+    }
+    return hipSuccess;
+}
+
 // launches [l0, l1); first: start of a factorization (timer, memset, assembly); last: its end (timer, status)
 static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool last, int sync) {
     if (!p->values_set) return SF_ERR_ARG;
@@ -887,6 +838,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             }
         }
         if (p->profiling) { kinds.push_back(L.kind); mark(); }
+        if (p->dl_active) HIP_TRY(dl_publish(p, li + 1));
     }
     if (last) HIP_TRY(hipEventRecord(p->ev1, st));
     HIP_TRY(hipGetLastError());
@@ -993,6 +945,138 @@ int sf_chol_plan_set_stream(sf_chol_plan* p, void* stream) {
 
 int sf_chol_plan_factorize(sf_chol_plan* p, int sync) { return sf_chol_plan_factorize_phase(p, -1, sync); }
 
+// ---------------------------------------------------------------------------------------------------
+// Overlapped copy-back.  The reference copies finished blocks back on a second stream while it computes
+// (s_cudaStream_copyback, C:2888-2895).  Here: DL_WORKERS host threads, each with its own HIP stream and two pinned
+// 32 MiB staging slots.  Worker w takes pieces w, w + W, ... (pieces are sorted by the launch that finishes them): it
+// waits until the main thread has recorded the piece's event on the compute stream, makes its stream wait for that
+// event, starts the D2H into one slot and, while that DMA runs, copies the previous slot into the caller's buffer.
+// The caller's memory is never pinned or registered: fresh (never touched) pages of a just-malloc'ed Lsx are faulted in
+// by the workers in parallel with the factorization (measured: hipHostRegister of fresh memory is a serial 0.06 s/GiB,
+// 1.7 s for the 128^3 factor; tools/host_xfer_bench.hip).
+// ---------------------------------------------------------------------------------------------------
+} // extern "C"
+
+#include <sys/mman.h>
+#include <unistd.h>
+
+static void dl_fail(sf_chol_plan* p, int code) {
+    int expect = 0;
+    p->dl_error.compare_exchange_strong(expect, code);
+    {
+        std::lock_guard<std::mutex> g(p->dl_mu);
+        p->dl_abort = true;
+    }
+    p->dl_cv.notify_all();
+}
+
+static void dl_worker(sf_chol_plan* p, int w) {
+    if (hipSetDevice(p->device) != hipSuccess) { dl_fail(p, SF_ERR_HIP); return; }
+    hipStream_t ws = p->dl_streams[w];
+    const size_t np = p->dl_pieces.size();
+    const DlPiece* prev = nullptr;
+    int prev_slot = 0, slot = 0;
+    auto drain = [&](const DlPiece* pc, int sl) -> bool {
+        if (hipEventSynchronize(p->dl_done[w][sl]) != hipSuccess) return false;
+        memcpy(p->dl_host + pc->host_off, p->h_ring + ((int64_t)w * 2 + sl) * DL_SLOT, (size_t)pc->count * sizeof(double));
+        return true;
+    };
+    for (size_t k = (size_t)w; k < np; k += DL_WORKERS) {
+        const DlPiece& pc = p->dl_pieces[k];
+        {
+            std::unique_lock<std::mutex> g(p->dl_mu);
+            p->dl_cv.wait(g, [&] { return p->dl_abort || p->dl_published > (size_t)pc.ev; });
+            if (p->dl_abort) return;
+        }
+        double* hslot = p->h_ring + ((int64_t)w * 2 + slot) * DL_SLOT;
+        bool ok = hipStreamWaitEvent(ws, p->dl_events[pc.ev], 0) == hipSuccess;
+        const double* src = p->d_Lsx + pc.dev_off;
+        if (ok && p->lu) {
+            double* dslot = p->d_ring + ((int64_t)w * 2 + slot) * DL_SLOT;
+            sf::launch_pack_lu(p->d_Super, p->d_Lsip, p->d_Xp, p->d_Lsxp, (int32_t)p->nsuper, p->d_Lsx, p->d_Lsx + p->xC,
+                               dslot, pc.host_off, pc.host_off + pc.count, ws);
+            ok = hipGetLastError() == hipSuccess;
+            src = dslot;
+        }
+        ok = ok && hipMemcpyAsync(hslot, src, (size_t)pc.count * sizeof(double), hipMemcpyDeviceToHost, ws) == hipSuccess;
+        ok = ok && hipEventRecord(p->dl_done[w][slot], ws) == hipSuccess;
+        if (ok && prev) ok = drain(prev, prev_slot);
+        if (!ok) { dl_fail(p, SF_ERR_HIP); return; }
+        prev = &pc;
+        prev_slot = slot;
+        slot ^= 1;
+    }
+    if (prev && !drain(prev, prev_slot)) dl_fail(p, SF_ERR_HIP);
+}
+
+int sf_dl_begin(sf_chol_plan* p, double* host_out) {
+    if (!p || !host_out || p->dl_active) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->h_ring) {
+        const size_t rb = (size_t)DL_WORKERS * 2 * DL_SLOT * sizeof(double);
+        HIP_TRY(hipHostMalloc((void**)&p->h_ring, rb, hipHostMallocDefault));
+        if (p->lu) {
+            HIP_TRY(hipMalloc((void**)&p->d_ring, rb));
+            p->bytes_device += rb;
+        }
+        for (int w = 0; w < DL_WORKERS; ++w) {
+            HIP_TRY(hipStreamCreateWithFlags(&p->dl_streams[w], hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&p->dl_done[w][k], hipEventDisableTiming));
+        }
+    }
+    // transparent huge pages for the destination (this box: THP = madvise): 512x fewer first-touch faults when the
+    // caller hands over a just-malloc'ed Lsx, harmless otherwise
+    if (p->xsize > 0) {
+        const uintptr_t pg = (uintptr_t)2 << 20;
+        const uintptr_t a = ((uintptr_t)host_out + pg - 1) & ~(pg - 1), b = ((uintptr_t)(host_out + p->xsize)) & ~(pg - 1);
+        if (b > a) (void)madvise((void*)a, b - a, MADV_HUGEPAGE);
+    }
+    p->dl_host = host_out;
+    p->dl_next_ev = 0;
+    p->dl_published = 0;
+    p->dl_abort = false;
+    p->dl_error.store(0);
+    p->dl_active = true;
+    p->dl_threads.clear();
+    const int nw = (int)std::min<size_t>(DL_WORKERS, p->dl_pieces.size());
+    for (int w = 0; w < nw; ++w) p->dl_threads.emplace_back(dl_worker, p, w);
+    return SF_OK;
+}
+
+int sf_dl_end(sf_chol_plan* p) {
+    if (!p || !p->dl_active) return SF_ERR_ARG;
+    // a factorization that stopped early (an error in the enqueue path) must still release the workers
+    if (p->dl_next_ev < p->dl_ev_ready.size()) {
+        if (hipSetDevice(p->device) != hipSuccess || dl_publish(p, p->launches.size()) != hipSuccess) dl_fail(p, SF_ERR_HIP);
+        if (p->dl_next_ev < p->dl_ev_ready.size()) dl_fail(p, SF_ERR_HIP);
+    }
+    for (std::thread& t : p->dl_threads) t.join();
+    p->dl_threads.clear();
+    p->dl_active = false;
+    p->dl_host = nullptr;
+    return p->dl_error.load();
+}
+
+extern "C" {
+
+// values H2D + numeric factorization + factor D2H into `host_out` (reference layout, xsize doubles), the download
+// overlapped with the computation.  What one SparseFrame_factorize call does once its plan exists.
+int sf_chol_plan_factorize_to_host(sf_chol_plan* p, const sf_float* Lx, const sf_float* Ux, sf_float* host_out) {
+    if (!p || (!host_out && p->xsize > 0) || p->nranks > 1) return SF_ERR_ARG;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int rc = p->lu ? sf_lu_plan_set_values(p, Lx, Ux) : sf_chol_plan_set_values(p, Lx);
+    if (rc) return rc;
+    if (p->xsize <= 0) return sf_chol_plan_factorize(p, 1);
+    if ((rc = sf_dl_begin(p, host_out))) return rc;
+    rc = sf_chol_plan_factorize(p, 0);
+    const int rc_dl = sf_dl_end(p);
+    const int rc_sync = sf_chol_plan_sync(p);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    p->last_to_host_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6;
+    return rc ? rc : (rc_sync ? rc_sync : rc_dl);
+}
+
 int sf_chol_plan_top_region(sf_chol_plan* p, void** dptr, sf_long* count) {
     if (!p || !dptr || !count) return SF_ERR_ARG;
     *dptr = (void*)(p->d_Lsx + p->top_off);
@@ -1032,7 +1116,7 @@ int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
         p->bytes_device += p->xsize * sizeof(double);
     }
     sf::launch_pack_lu(p->d_Super, p->d_Lsip, p->d_Xp, p->d_Lsxp, (int32_t)p->nsuper, p->d_Lsx, p->d_Lsx + p->xC,
-                       p->d_pack, p->xsize, p->stream);
+                       p->d_pack, 0, p->xsize, p->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy(Lsx, p->d_pack, p->xsize * sizeof(double), hipMemcpyDeviceToHost));
@@ -1060,6 +1144,8 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     const std::string k(name);
     if (k == "levels") return p->nlevels;
     if (k == "last_solve_ms") return p->last_solve_ms;
+    if (k == "last_to_host_ms") return p->last_to_host_ms;
+    if (k == "download_pieces") return (double)p->dl_pieces.size();
     if (k == "top_doubles") return (double)p->top_size;
     if (k == "stored_doubles") return (double)p->xC;
     if (k == "launches") return (double)p->launches.size();
@@ -1116,77 +1202,6 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     float ms = 0;
     if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) p->last_solve_ms = ms;
     return SF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// struct-based entry points of the device side
-// ---------------------------------------------------------------------------------------------------
-struct gpu_info_struct {
-    int gpuIndex_physical;
-    size_t devMemSize;
-};
-
-int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {
-    if (!common || !list) return 1;
-    int ndev = sf_device_count();
-    common->numGPU_physical = ndev;
-    common->numGPU = ndev;       // one handler per device; no virtual-GPU splitting (reference C:36-41)
-    common->numCPU = 0;          // the numeric phase has no CPU worker
-    common->minDevMemSize = 0;
-    common->minHostMemSize = 0;
-    *list = (struct gpu_info_struct*)calloc(ndev > 0 ? ndev : 1, sizeof(struct gpu_info_struct));
-    if (!*list) return 1;
-    size_t min_mem = (size_t)-1;
-    for (int d = 0; d < ndev; ++d) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
-        (*list)[d].gpuIndex_physical = d;
-        (*list)[d].devMemSize = prop.totalGlobalMem;
-        min_mem = std::min(min_mem, (size_t)prop.totalGlobalMem);
-    }
-    if (ndev > 0 && min_mem != (size_t)-1) {
-        common->devSlotSize = sf_reference_slot_size(ndev, min_mem);
-        common->minDevMemSize = common->devSlotSize * 8;
-    } else {
-        const char* env = getenv("SF_DEVSLOT");
-        common->devSlotSize = env ? (size_t)strtoull(env, nullptr, 10) : ((size_t)1 << 30);
-    }
-    return 0;
-}
-
-int SparseFrame_free_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {
-    if (!list || !*list) return 1;
-    free(*list);
-    *list = nullptr;
-    if (common) common->numGPU = 0;
-    return 0;
-}
-
-int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct gpu_info_struct* list,
-                                     struct matrix_info_struct* mi) {
-    if (!common || !mi || !mi->Lsx) return SF_ERR_ARG;
-    if (common->numGPU <= 0 || !list) {
-        fprintf(stderr, "[sparseframe-hip] SparseFrame_factorize: no GPU handler (numGPU = %d); no CPU fallback\n", common->numGPU);
-        return SF_ERR_NO_DEVICE;
-    }
-    sf_chol_plan* plan = nullptr;
-    int rc = sf_chol_plan_create(&plan, list[0].gpuIndex_physical, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap,
-                                 mi->Lsip, mi->Lsi, mi->Lsxp, mi->Lp, mi->Li);
-    if (rc) return rc;
-    rc = sf_chol_plan_set_values(plan, mi->Lx);
-    if (!rc) rc = sf_chol_plan_factorize(plan, 1);
-    int rc2 = sf_chol_plan_get_factor(plan, mi->Lsx);
-    sf_chol_plan_destroy(plan);
-    return rc ? rc : rc2;
-}
-
-int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {
-    struct timespec a, b;
-    clock_gettime(CLOCK_REALTIME, &a);
-    const int rc = SparseFrame_factorize_supernodal(common, list, mi);
-    clock_gettime(CLOCK_REALTIME, &b);
-    if (mi) mi->factorizeTime = (b.tv_sec - a.tv_sec) + (b.tv_nsec - a.tv_nsec) / 1.0e9;
-    return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,207 @@
+// Device handlers behind the reference's struct entry points (SparseFrame_allocate_gpu C:16-285, _free_gpu C:287-366,
+// _factorize_supernodal C:2150-3017, _factorize C:3019-3034; the LU library forwards here too).
+//
+// The reference builds, per device handler, eight equal device slots plus pinned mirrors and streams, and stages every
+// panel through them.  Here a handler owns
+//   * a lock (the reference's gpuLock, C:2287: MATRIX_THREAD_NUM callers share the handler list),
+//   * a small cache of device plans keyed by a hash of the symbolic pattern: the task tables, the relative maps and the
+//     resident factor are built once per pattern and re-used by every later factorization of that pattern,
+// and a factorization is: values H2D, the level-scheduled numeric phase, and the factor copied back into
+// matrix_info->Lsx WHILE the upper levels still compute (sf_chol_plan_factorize_to_host; reference C:2888-2895).
+#include <sparseframe_hip.h>
+
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "sf_plan_internal.h"
+
+namespace {
+
+struct PlanKey {
+    uint64_t h = 0;
+    int64_t n = 0, nsuper = 0, isize = 0, xsize = 0, nnz = 0, unz = 0;
+    int lu = 0;
+    bool operator==(const PlanKey& o) const {
+        return h == o.h && n == o.n && nsuper == o.nsuper && isize == o.isize && xsize == o.xsize && nnz == o.nnz && unz == o.unz && lu == o.lu;
+    }
+};
+
+// 64-bit multiply-xorshift hash over 8-byte words, four independent lanes (memory-bound: ~10 GB/s per thread)
+uint64_t hash_words(const int64_t* a, int64_t n, uint64_t seed) {
+    const uint64_t M = 0x9E3779B97F4A7C15ull;
+    uint64_t h0 = seed ^ 0x1234567ull, h1 = seed + 0x9abcdefull, h2 = ~seed, h3 = seed * M;
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        h0 = (h0 ^ (uint64_t)a[i]) * M;     h0 ^= h0 >> 29;
+        h1 = (h1 ^ (uint64_t)a[i + 1]) * M; h1 ^= h1 >> 31;
+        h2 = (h2 ^ (uint64_t)a[i + 2]) * M; h2 ^= h2 >> 27;
+        h3 = (h3 ^ (uint64_t)a[i + 3]) * M; h3 ^= h3 >> 33;
+    }
+    for (; i < n; ++i) { h0 = (h0 ^ (uint64_t)a[i]) * M; h0 ^= h0 >> 29; }
+    uint64_t h = h0;
+    h = (h ^ h1) * M; h ^= h >> 32;
+    h = (h ^ h2) * M; h ^= h >> 32;
+    h = (h ^ h3) * M; h ^= h >> 32;
+    return h;
+}
+
+// the arrays a plan depends on: Super, Lsip, Lsxp, Lsi (the symbolic factor) and Lp, Li (Up, Ui) (where the matrix entries go);
+// the two long ones (Lsi, Li) are hashed by their own threads
+PlanKey make_key(int lu, sf_long n, sf_long nsuper, const sf_long* Super, const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                 const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui) {
+    PlanKey k;
+    k.lu = lu; k.n = n; k.nsuper = nsuper; k.isize = Lsip[nsuper]; k.xsize = Lsxp[nsuper]; k.nnz = Lp[n];
+    k.unz = (lu && Up) ? Up[n] : 0;
+    uint64_t hl = 0, hi = 0, hu = 0;
+    std::thread t1([&] { hl = hash_words(Lsi, k.isize, 11); });
+    std::thread t2([&] { hi = hash_words(Li, k.nnz, 13); });
+    std::thread t3([&] { if (k.unz) hu = hash_words(Ui, k.unz, 17) ^ hash_words(Up, n + 1, 19); });
+    uint64_t h = hash_words(Super, nsuper + 1, 1);
+    h ^= hash_words(Lsip, nsuper + 1, 3) * 3;
+    h ^= hash_words(Lsxp, nsuper + 1, 5) * 5;
+    h ^= hash_words(Lp, n + 1, 7) * 7;
+    t1.join(); t2.join(); t3.join();
+    k.h = h ^ (hl * 11) ^ (hi * 13) ^ (hu * 17);
+    return k;
+}
+
+struct HandlerState {
+    std::mutex mu;
+    struct Entry { PlanKey key; sf_chol_plan* plan; uint64_t stamp; };
+    std::vector<Entry> cache;
+    uint64_t clock = 0;
+    ~HandlerState() {
+        for (Entry& e : cache) sf_chol_plan_destroy(e.plan);
+    }
+};
+constexpr size_t MAX_CACHED_PLANS = 2;      // per handler: MATRIX_THREAD_NUM = 2 matrices in flight in the reference's driver
+
+}  // namespace
+
+struct gpu_info_struct {
+    int gpuIndex_physical;
+    size_t devMemSize;
+    HandlerState* st;
+};
+
+extern "C" {
+
+int sf_handlers_allocate(struct common_info_struct* common, struct gpu_info_struct** list) {
+    if (!common || !list) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    int ndev = sf_device_count();
+    common->numGPU_physical = ndev;
+    common->numGPU = ndev;       // one handler per device; no virtual-GPU splitting (reference C:36-41)
+    common->numCPU = 0;          // the numeric phase has no CPU worker
+    common->minDevMemSize = 0;
+    common->minHostMemSize = 0;
+    *list = (struct gpu_info_struct*)calloc(ndev > 0 ? ndev : 1, sizeof(struct gpu_info_struct));
+    if (!*list) return 1;
+    size_t min_mem = (size_t)-1;
+    for (int d = 0; d < ndev; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+        (*list)[d].gpuIndex_physical = d;
+        (*list)[d].devMemSize = prop.totalGlobalMem;
+        (*list)[d].st = new (std::nothrow) HandlerState();
+        min_mem = std::min(min_mem, (size_t)prop.totalGlobalMem);
+    }
+    if (ndev > 0 && min_mem != (size_t)-1) {
+        common->devSlotSize = sf_reference_slot_size(ndev, min_mem);
+        common->minDevMemSize = common->devSlotSize * 8;
+    } else {
+        const char* env = getenv("SF_DEVSLOT");
+        common->devSlotSize = env ? (size_t)strtoull(env, nullptr, 10) : ((size_t)1 << 30);
+    }
+    common->allocateTime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int sf_handlers_free(struct common_info_struct* common, struct gpu_info_struct** list) {
+    if (!list || !*list) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int nh = common ? std::max(common->numGPU, 0) : 0;
+    for (int d = 0; d < nh; ++d) {
+        delete (*list)[d].st;           // destroys the cached plans (device memory, pinned rings)
+        (*list)[d].st = nullptr;
+    }
+    free(*list);
+    *list = nullptr;
+    if (common) {
+        common->numGPU = 0;
+        common->freeTime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+// One numeric factorization through the handler list.  Returns SF_OK or an SF_ERR_* code; Lsx_out receives the factor in
+// the reference layout.
+int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_struct* list, int lu, int serial,
+                          sf_long n, sf_long nsuper, const sf_long* Super, const sf_long* SuperMap,
+                          const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                          const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
+                          const sf_float* Lx, const sf_float* Ux, sf_float* Lsx_out) {
+    if (!common || !Lsx_out || !Super || !Lsip || !Lsxp || !Lp || n < 0 || nsuper < 0) return SF_ERR_ARG;
+    if (common->numGPU <= 0 || !list) {
+        fprintf(stderr, "[sparseframe-hip] SparseFrame_factorize: no GPU handler (numGPU = %d); no CPU fallback\n", common->numGPU);
+        return SF_ERR_NO_DEVICE;
+    }
+    if (n > 0 && (!SuperMap || !Lsi || !Li)) return SF_ERR_ARG;
+    // one matrix = one handler; the caller's matrix threads (MATRIX_THREAD_NUM, C:3375) are spread over the devices
+    struct gpu_info_struct& H = list[(serial >= 0 ? serial : 0) % common->numGPU];
+    if (!H.st) return SF_ERR_NO_DEVICE;
+    const PlanKey key = make_key(lu, n, nsuper, Super, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui);
+    std::lock_guard<std::mutex> guard(H.st->mu);
+    HandlerState& S = *H.st;
+    sf_chol_plan* plan = nullptr;
+    for (HandlerState::Entry& e : S.cache)
+        if (e.key == key) { plan = e.plan; e.stamp = ++S.clock; break; }
+    if (!plan) {
+        auto create = [&]() {
+            return lu ? sf_lu_plan_create(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui)
+                      : sf_chol_plan_create(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li);
+        };
+        // make room first when the cache is full; when the device is out of memory, drop everything cached and retry once
+        while (S.cache.size() >= MAX_CACHED_PLANS) {
+            size_t lru = 0;
+            for (size_t i = 1; i < S.cache.size(); ++i)
+                if (S.cache[i].stamp < S.cache[lru].stamp) lru = i;
+            sf_chol_plan_destroy(S.cache[lru].plan);
+            S.cache.erase(S.cache.begin() + lru);
+        }
+        int rc = create();
+        if ((rc == SF_ERR_ALLOC || rc == SF_ERR_HIP) && !S.cache.empty()) {
+            for (HandlerState::Entry& e : S.cache) sf_chol_plan_destroy(e.plan);
+            S.cache.clear();
+            (void)hipGetLastError();
+            rc = create();
+        }
+        if (rc) return rc;
+        S.cache.push_back(HandlerState::Entry{key, plan, ++S.clock});
+    }
+    return sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
+}
+
+int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_allocate(common, list); }
+int SparseFrame_free_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_free(common, list); }
+
+int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct gpu_info_struct* list,
+                                     struct matrix_info_struct* mi) {
+    if (!common || !mi || !mi->Lsx) return SF_ERR_ARG;
+    return sf_handlers_factorize(common, list, 0, mi->serial, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi,
+                                 mi->Lsxp, mi->Lp, mi->Li, nullptr, nullptr, mi->Lx, nullptr, mi->Lsx);
+}
+
+int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {
+    struct timespec a, b;
+    clock_gettime(CLOCK_REALTIME, &a);
+    const int rc = SparseFrame_factorize_supernodal(common, list, mi);
+    clock_gettime(CLOCK_REALTIME, &b);
+    if (mi) mi->factorizeTime = (b.tv_sec - a.tv_sec) + (b.tv_nsec - a.tv_nsec) / 1.0e9;
+    return rc;
+}
+
+}  // extern "C"

@@ -82,9 +82,10 @@ void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hi
 // LU: the diagonal block is split over two panels, L (strictly lower, at Lsx + task.panel) and U^T (lower
 // including the diagonal, at Lsx + task.panel + u_shift)
 void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, hipStream_t st);
-// LU: gather the (L, U^T) panel pairs into the reference's (2*nsrow - nscol) x nscol panels (LU/Source/SparseFrame.c:2514-2517)
+// LU: gather the (L, U^T) panel pairs into the reference's (2*nsrow - nscol) x nscol panels (LU/Source/SparseFrame.c:2514-2517):
+// values [e_begin, e_end) of that layout -> out[0 .. e_end - e_begin)
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
-                    const double* PL, const double* PU, double* out, int64_t ref_size, hipStream_t st);
+                    const double* PL, const double* PU, double* out, int64_t e_begin, int64_t e_end, hipStream_t st);
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
 // tasks: the diagonal blocks first, then the 64-row tiles below them, any number (the grid need not be co-resident:
 // workgroups claim tasks in execution order through *ticket, which must be 0 at launch and is private to the launch);

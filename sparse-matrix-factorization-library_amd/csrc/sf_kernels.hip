@@ -183,15 +183,17 @@ void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shi
 __global__ void __launch_bounds__(256)
 k_pack_lu(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsip, const int64_t* __restrict__ Xp,
           const int64_t* __restrict__ RefXp, int32_t nsuper, const double* __restrict__ PL, const double* __restrict__ PU,
-          double* __restrict__ out, int64_t ref_size) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ref_size; e += (int64_t)gridDim.x * blockDim.x) {
+          double* __restrict__ out, int64_t e_begin, int64_t e_end) {
+    // values [e_begin, e_end) of the reference layout -> out[0 .. e_end - e_begin)
+    for (int64_t e = e_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += (int64_t)gridDim.x * blockDim.x) {
+        double* __restrict__ dst = out + (e - e_begin);
         int lo = 0, hi = nsuper;            // largest s with RefXp[s] <= e
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (RefXp[mid] <= e) lo = mid; else hi = mid;
         }
         const int s = lo;
-        if (Xp[s] < 0) { out[e] = 0.0; continue; }      // sharded plan: the panel lives on another rank
+        if (Xp[s] < 0) { *dst = 0.0; continue; }      // sharded plan: the panel lives on another rank
         const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
         const int64_t lda = 2 * nsrow - nscol;
         const int64_t off = e - RefXp[s];
@@ -201,16 +203,16 @@ k_pack_lu(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsip, c
         if (R < nscol) v = (R > j) ? pl[R] : PU[Xp[s] + j + R * nsrow];          // packed L11 \ U11: U(R,j) = PU(j,R)
         else if (R < nsrow) v = pl[R];                                             // L21
         else v = PU[Xp[s] + (R - nsrow + nscol) + j * nsrow];                      // U12^T
-        out[e] = v;
+        *dst = v;
     }
 }
 
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
-                    const double* PL, const double* PU, double* out, int64_t ref_size, hipStream_t st) {
-    if (ref_size <= 0) return;
-    const int64_t blocks = (ref_size + 255) / 256;
+                    const double* PL, const double* PU, double* out, int64_t e_begin, int64_t e_end, hipStream_t st) {
+    if (e_end <= e_begin) return;
+    const int64_t blocks = (e_end - e_begin + 255) / 256;
     hipLaunchKernelGGL(k_pack_lu, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
-                       Super, Lsip, Xp, RefXp, nsuper, PL, PU, out, ref_size);
+                       Super, Lsip, Xp, RefXp, nsuper, PL, PU, out, e_begin, e_end);
 }
 
 // ---------------------------------------------------------------------------------------------------

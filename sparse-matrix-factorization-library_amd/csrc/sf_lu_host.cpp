@@ -42,11 +42,6 @@ sf_float* dup_float(const sf_symbolic* S, const char* name) {
 
 }  // namespace
 
-struct gpu_info_struct {
-    int gpuIndex_physical;
-    size_t devMemSize;
-};
-
 extern "C" {
 
 long sf_lu_abi_layout(const char* name) {
@@ -61,39 +56,9 @@ long sf_lu_abi_layout(const char* name) {
     return -1;
 }
 
-int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {   // L:16-285
-    if (!common || !list) return 1;
-    const int ndev = sf_device_count();
-    common->numGPU_physical = ndev;
-    common->numGPU = ndev;
-    common->numCPU = 0;
-    common->minHostMemSize = 0;
-    *list = (struct gpu_info_struct*)calloc(ndev > 0 ? ndev : 1, sizeof(struct gpu_info_struct));
-    if (!*list) return 1;
-    size_t min_mem = (size_t)-1;
-    for (int d = 0; d < ndev; ++d) {
-        (*list)[d].gpuIndex_physical = d;
-        (*list)[d].devMemSize = sf_device_memory(d);
-        if ((*list)[d].devMemSize < min_mem) min_mem = (*list)[d].devMemSize;
-    }
-    if (ndev > 0) {
-        common->devSlotSize = sf_reference_slot_size(ndev, min_mem);
-        common->minDevMemSize = common->devSlotSize * 8;
-    } else {
-        const char* env = getenv("SF_DEVSLOT");
-        common->devSlotSize = env ? (size_t)strtoull(env, nullptr, 10) : ((size_t)1 << 30);
-        common->minDevMemSize = 0;
-    }
-    return 0;
-}
-
-int SparseFrame_free_gpu(struct common_info_struct* common, struct gpu_info_struct** list) {   // L:287-366
-    if (!list || !*list) return 1;
-    free(*list);
-    *list = nullptr;
-    if (common) common->numGPU = 0;
-    return 0;
-}
+// the handler list is the main library's (sf_handlers.hip): one handler per device, plan cache, overlapped copy-back
+int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_allocate(common, list); }   // L:16-285
+int SparseFrame_free_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_free(common, list); }       // L:287-366
 
 int SparseFrame_initialize_matrix(struct matrix_info_struct* mi) {   // L:675-746
     if (!mi) return 1;
@@ -248,20 +213,9 @@ int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_st
 int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct gpu_info_struct* list,
                                      struct matrix_info_struct* mi) {   // L:2668-3573
     if (!common || !mi || !mi->Lsx) return SF_ERR_ARG;
-    if (common->numGPU <= 0 || !list) {
-        fprintf(stderr, "[sparseframe-hip] SparseFrame_factorize (LU): no GPU handler; no CPU fallback\n");
-        return SF_ERR_NO_DEVICE;
-    }
-    sf_lu_plan* plan = nullptr;
-    int rc = sf_lu_plan_create(&plan, list[0].gpuIndex_physical, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap,
-                               mi->Lsip, mi->Lsi, mi->Lsxp, mi->Lp, mi->Li,
-                               mi->isSymmetric ? nullptr : mi->Up, mi->isSymmetric ? nullptr : mi->Ui);
-    if (rc) return rc;
-    rc = sf_lu_plan_set_values(plan, mi->Lx, mi->isSymmetric ? nullptr : mi->Ux);
-    if (!rc) rc = sf_lu_plan_factorize(plan, 1);
-    const int rc2 = sf_lu_plan_get_factor(plan, mi->Lsx);
-    sf_lu_plan_destroy(plan);
-    return rc ? rc : rc2;
+    return sf_handlers_factorize(common, list, 1, mi->serial, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi,
+                                 mi->Lsxp, mi->Lp, mi->Li, mi->isSymmetric ? nullptr : mi->Up, mi->isSymmetric ? nullptr : mi->Ui,
+                                 mi->Lx, mi->isSymmetric ? nullptr : mi->Ux, mi->Lsx);
 }
 
 int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {

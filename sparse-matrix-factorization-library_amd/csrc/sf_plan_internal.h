@@ -1,0 +1,179 @@
+// Private view of the device plan shared by the translation units of libsparseframe_hip.so (not part of the C ABI).
+#pragma once
+#include <sparseframe_hip.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "sf_kernels.h"
+
+using sf::GemmProb;
+using sf::GemmTask;
+using sf::PotrfTask;
+using sf::TrsmTask;
+using sf::StepTask;
+
+struct Launch {
+    int kind;       // 0 potrf, 1 trsm, 2 gemm panel (inner, K = NB), 3 gemm scatter, 4 gemm panel (outer, large K),
+                    // 6 Schur updates with K <= SU_MAXK (k_update_small, tasks in stasks),
+                    // 5 fused step k_step (Cholesky, steps of at most GEMM_GRID workgroups; otherwise and for LU: 2, 0, 1)
+    int64_t first;  // first task
+    int count;
+    int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
+    uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
+    double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
+    bool split = false;         // distributed top: every rank executes 1/nranks of this launch's units
+    int ticket = 0;             // k_step launches: index of the launch's task-claim counter (d_info[1 + ticket])
+};
+
+// Distributed top phase (sf_chol_plan_create_distributed): phase 1 is cut into segments.  Before a segment runs, the
+// regions it lists (the 512-column block of every top panel of the level whose 64-column chain is about to start) are
+// summed over the ranks; until then a block only ever received additive updates (subtree Schur updates, split top
+// Schur updates, split outer GEMMs), so its true value is the sum of the ranks' copies.
+struct Segment {
+    size_t l0 = 0, l1 = 0;                 // launches [l0, l1)
+    std::vector<int64_t> off, cnt;         // whole block columns: doubles, relative to the factor base pointer
+    // the part of each region that can be non-zero (rows >= the block's first column): `cols` pieces of `rows` doubles,
+    // `ld` apart, starting at `src` -- what sf_chol_plan_segment_pack gathers into one contiguous buffer
+    std::vector<int64_t> src, rows, cols, ld;
+    int64_t packed = 0;                    // doubles in the packed buffer
+};
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            fprintf(stderr, "[sparseframe-hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SF_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+template <class T>
+static inline int upload(T** dptr, const std::vector<T>& h, size_t* bytes_total) {
+    *dptr = nullptr;
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dptr, bytes));
+    if (!h.empty()) HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes_total += bytes;
+    return SF_OK;
+}
+
+// Overlapped copy-back of the factor (sf_chol_plan_factorize_to_host; the reference overlaps the D2H of finished blocks
+// with compute on s_cudaStream_copyback, C:2888-2895).  A piece is a run of finished panel columns that is contiguous in
+// the host layout (and, for Cholesky, in the device layout), at most DL_SLOT doubles; it may be copied once launch
+// `ready` - 1 has completed (event `ev`).  Pieces are sorted by `ready`.
+constexpr int64_t DL_SLOT = (int64_t)4 << 20;      // doubles per staging slot (32 MiB)
+constexpr int DL_WORKERS = 6;                      // copy workers: own HIP stream + 2 pinned slots each
+struct DlPiece {
+    int64_t dev_off, host_off, count;   // doubles; LU: dev_off unused (the piece is packed from the (L, U^T) panels)
+    size_t ready;
+    int ev;
+};
+
+struct sf_chol_plan {
+    // ---- overlapped download schedule (built once) and the state of a running download ----
+    std::vector<DlPiece> dl_pieces;
+    std::vector<size_t> dl_ev_ready;            // launch count after which event k is recorded
+    std::vector<hipEvent_t> dl_events;
+    bool dl_active = false;                     // run_launches records the events and publishes them
+    size_t dl_next_ev = 0;
+    std::mutex dl_mu;
+    std::condition_variable dl_cv;
+    size_t dl_published = 0;                    // events [0, dl_published) have been recorded (guarded by dl_mu)
+    bool dl_abort = false;
+    double* h_ring = nullptr;                   // pinned staging ring: DL_WORKERS x 2 slots
+    double* d_ring = nullptr;                   // LU: device staging of packed pieces, same shape
+    hipStream_t dl_streams[DL_WORKERS] = {};
+    hipEvent_t dl_done[DL_WORKERS][2] = {};
+    double last_to_host_ms = 0;                 // wall time of the last sf_chol_plan_factorize_to_host
+    std::vector<std::thread> dl_threads;
+    std::atomic<int> dl_error{0};
+    double* dl_host = nullptr;                  // destination of the running download (reference layout)
+    bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
+    int64_t xC = 0;             // doubles in one set of nsrow x nscol panels (Cholesky: == xsize)
+    int64_t unz = 0;            // LU: entries of U (by row)
+    int64_t* d_Up = nullptr;    // LU, unsymmetric input: U by row
+    int32_t* d_Ui = nullptr;
+    double* d_Ux = nullptr;
+    int64_t* d_Xp = nullptr;    // LU: offsets of the nsrow x nscol panels (the reference's Lsxp has the packed sizes)
+    double* d_pack = nullptr;   // LU: staging buffer in the reference layout for the download
+    bool u_alias = false;       // LU with a symmetric input: U aliases L (reference L:2718-2729)
+    // multi-GPU sharding: phase[s] = 0 owned subtree supernode, 1 top supernode (replicated), -1 not on this rank
+    std::vector<int8_t> phase;
+    std::vector<int64_t> h_XP;  // device panel offsets (doubles), -1 when the panel is not stored on this rank
+    bool partial = false;       // some supernodes are absent or the top panels are not loaded here
+    int64_t top_off = 0, top_size = 0;   // contiguous region of the top panels inside one panel set
+    size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
+    int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
+    std::vector<Segment> segments;
+    double* d_scratch = nullptr;   // packed segment buffer (max over the segments)
+    int64_t packed_pending = -1;   // segment whose packed buffer has to be scattered back before it runs
+    bool own_stream = true;
+    int8_t* d_loadmask = nullptr;
+    // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
+    sf::SolveTask* d_solve = nullptr;
+    double* d_x = nullptr;
+    struct SolveStep { int64_t diag_first; int diag_count; int64_t fwd_first; int fwd_count; int64_t bwd_first; int bwd_count; };
+    std::vector<SolveStep> solve_steps;
+    double last_solve_ms = 0;
+    int device = 0;
+    int64_t n = 0, nsuper = 0, nnz = 0, isize = 0, xsize = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+
+    // device copies of the structure
+    int64_t* d_Lp = nullptr;
+    int32_t* d_Li = nullptr;
+    double* d_Lx = nullptr;
+    int32_t* d_Super = nullptr;
+    int32_t* d_SuperMap = nullptr;
+    int64_t* d_Lsip = nullptr;
+    int32_t* d_Lsi = nullptr;
+    int64_t* d_Lsxp = nullptr;
+    double* d_Lsx = nullptr;
+    int* d_info = nullptr;      // [0]: status bits of the running factorization; [1 ..]: task-claim counters of the k_step launches
+    int n_tickets = 0;
+
+    PotrfTask* d_potrf = nullptr;
+    TrsmTask* d_trsm = nullptr;
+    StepTask* d_steps = nullptr;
+    int* d_flags = nullptr;     // k_step: one flag per (panel, fused step); == epoch once its diagonal block is factored
+    double* d_tinv = nullptr;   // k_step: inverses of the 16 x 16 diagonal sub-blocks, per diagonal task of the running launch
+    int epoch = 0;
+    GemmProb* d_probs = nullptr;
+    GemmTask* d_gtasks = nullptr;
+    GemmTask* d_stasks = nullptr;   // tiles of k_update_small
+    uint32_t* d_ktprefix = nullptr;
+    int32_t* d_relmap = nullptr;
+
+    std::vector<Launch> launches;
+    int nlevels = 0;
+    int64_t n_gemm_tasks = 0, n_pairs = 0;
+    double flops_update_small = 0;      // part of flops_update done by k_update_small (K <= SU_MAXK)
+    double flops_exec = 0, flops_update = 0, scatter_elems = 0, flops_panel_gemm = 0, flops_outer_gemm = 0;
+    size_t bytes_device = 0;
+    bool values_set = false;
+
+    bool profiling = false;
+    double last_ms = 0, last_load_ms = 0, last_panel_ms = 0, last_update_ms = 0;
+    double last_kind_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    int last_status = SF_OK;
+
+    // host copies needed by the device solve
+    std::vector<int64_t> h_Lsip, h_Lsxp;
+    std::vector<int32_t> h_Super;
+    std::vector<int> level_of;
+};
+
+
+// Overlapped download (sf_chol_plan.hip).  sf_dl_begin starts the copy workers of a factorization whose launches are
+// about to be enqueued with run_launches (which records and publishes the piece events while dl_active is set);
+// sf_dl_end publishes what is left, waits for the workers and returns SF_OK or the first error.
+int sf_dl_begin(sf_chol_plan* p, double* host_out);
+int sf_dl_end(sf_chol_plan* p);

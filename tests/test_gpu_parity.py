@@ -401,3 +401,54 @@ def test_two_plans_concurrently_on_one_gpu(oracle):
         Lsx = p.get_factor()
         assert rel_err(Lsx, ref * np.sqrt(1.0 + k), mask) <= TOL_FACTOR
         p.close()
+
+
+def test_factorize_to_host_overlapped_download(oracle):
+    """sf_chol_plan_factorize_to_host: the factor copied back piece by piece while the upper levels compute must be the
+    factor a plain factorize + get_factor returns, bit for bit where the kernels are deterministic (no atomics race on a
+    single panel chain) and to rounding elsewhere; run twice (the plan, its pinned ring and the piece events are re-used)"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(24, 24, 24)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(24, 24, 24), 8 << 30)
+    plan = sf.CholPlan(sym, device=0)
+    assert plan.stat("download_pieces") >= 1
+    ref, info, _ = oracle.chol_factorize(sym)
+    mask = oracle.lower_mask(sym)
+    out = np.full(sym.xsize, np.nan)
+    for scale in (1.0, 2.0):
+        got = plan.factorize_to_host(sym.Lx * scale, out)
+        assert not np.isnan(got[mask]).any()
+        assert rel_err(got, ref * np.sqrt(scale), mask) <= TOL_FACTOR
+        assert plan.stat("last_to_host_ms") > 0
+    plan.close()
+
+
+def test_struct_entry_point_reuses_cached_plan(oracle):
+    """SparseFrame_factorize twice on one handler list with the same pattern and new values: the second call finds the
+    plan in the handler's cache (no rebuild) and still returns the right factor; a third matrix with another pattern
+    evicts nothing it should not"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(16, 16, 16)
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    perm = sf.grid_nd_perm(16, 16, 16)
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
+    ref, info, _ = oracle.chol_factorize(sym)
+    mask = oracle.lower_mask(sym)
+    times = []
+    for scale in (1.0, 4.0, 9.0):
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx * scale)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        mi.factorize(common)
+        times.append(mi.c.factorizeTime)
+        assert rel_err(mi.array("Lsx", sym.xsize).copy(), ref * np.sqrt(scale), mask) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    n2, Cp2, Ci2, Cx2 = gen.laplacian_lower(30, 30)
+    mi = sf.MatrixInfo()
+    mi.set_csc(n2, Cp2, Ci2, Cx2)
+    mi.analyze(common)
+    mi.factorize(common)
+    assert mi.validate() <= TOL_RESIDUAL
+    mi.cleanup()
+    common.close()
+    assert times[1] < times[0] and times[2] < times[0]          # the plan was built once
