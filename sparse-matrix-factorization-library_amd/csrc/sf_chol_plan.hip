@@ -70,7 +70,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (p->ev_s1) (void)hipEventDestroy(p->ev_s1);
     for (hipEvent_t e : p->dl_events)
         if (e) (void)hipEventDestroy(e);
-    for (int w = 0; w < DL_WORKERS; ++w) {
+    for (int w = 0; w < DL_WORKERS_MAX; ++w) {
         if (p->dl_streams[w]) (void)hipStreamDestroy(p->dl_streams[w]);
         for (int k = 0; k < 2; ++k)
             if (p->dl_done[w][k]) (void)hipEventDestroy(p->dl_done[w][k]);
@@ -536,6 +536,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // one staging slot, larger runs cut into slot-sized pieces.  Top panels of a sharded plan are identical on every
     // rank once factored: their pieces are dealt out over the ranks so that every PCIe link carries a share.
     {
+        if (const char* env = getenv("SF_DL_WORKERS")) p->dl_workers = std::max(1, std::min(DL_WORKERS_MAX, atoi(env)));
+        if (const char* env = getenv("SF_DL_SLOT_MB")) p->dl_slot = (int64_t)std::max(1, atoi(env)) << 17;
+        const int64_t DL_SLOT = p->dl_slot;
         std::vector<DlPiece> runs;
         int last_phase = -2;
         for (sf_long s = 0; s < nsuper; ++s) {
@@ -970,24 +973,36 @@ static void dl_fail(sf_chol_plan* p, int code) {
     p->dl_cv.notify_all();
 }
 
+static double dl_now() {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec / 1e6;
+}
+
 static void dl_worker(sf_chol_plan* p, int w) {
     if (hipSetDevice(p->device) != hipSuccess) { dl_fail(p, SF_ERR_HIP); return; }
     hipStream_t ws = p->dl_streams[w];
     const size_t np = p->dl_pieces.size();
-    const DlPiece* prev = nullptr;
+    const int64_t DL_SLOT = p->dl_slot;
+    const int W = p->dl_workers;
+    size_t prev = np;
     int prev_slot = 0, slot = 0;
-    auto drain = [&](const DlPiece* pc, int sl) -> bool {
+    auto drain = [&](size_t k, int sl) -> bool {
+        const DlPiece& pc = p->dl_pieces[k];
         if (hipEventSynchronize(p->dl_done[w][sl]) != hipSuccess) return false;
-        memcpy(p->dl_host + pc->host_off, p->h_ring + ((int64_t)w * 2 + sl) * DL_SLOT, (size_t)pc->count * sizeof(double));
+        if (!p->dl_trace.empty()) p->dl_trace[3 * k + 1] = dl_now() - p->dl_t0;
+        memcpy(p->dl_host + pc.host_off, p->h_ring + ((int64_t)w * 2 + sl) * DL_SLOT, (size_t)pc.count * sizeof(double));
+        if (!p->dl_trace.empty()) p->dl_trace[3 * k + 2] = dl_now() - p->dl_t0;
         return true;
     };
-    for (size_t k = (size_t)w; k < np; k += DL_WORKERS) {
+    for (size_t k = (size_t)w; k < np; k += W) {
         const DlPiece& pc = p->dl_pieces[k];
         {
             std::unique_lock<std::mutex> g(p->dl_mu);
             p->dl_cv.wait(g, [&] { return p->dl_abort || p->dl_published > (size_t)pc.ev; });
             if (p->dl_abort) return;
         }
+        if (!p->dl_trace.empty()) p->dl_trace[3 * k] = dl_now() - p->dl_t0;
         double* hslot = p->h_ring + ((int64_t)w * 2 + slot) * DL_SLOT;
         bool ok = hipStreamWaitEvent(ws, p->dl_events[pc.ev], 0) == hipSuccess;
         const double* src = p->d_Lsx + pc.dev_off;
@@ -1000,26 +1015,26 @@ static void dl_worker(sf_chol_plan* p, int w) {
         }
         ok = ok && hipMemcpyAsync(hslot, src, (size_t)pc.count * sizeof(double), hipMemcpyDeviceToHost, ws) == hipSuccess;
         ok = ok && hipEventRecord(p->dl_done[w][slot], ws) == hipSuccess;
-        if (ok && prev) ok = drain(prev, prev_slot);
+        if (ok && prev < np) ok = drain(prev, prev_slot);
         if (!ok) { dl_fail(p, SF_ERR_HIP); return; }
-        prev = &pc;
+        prev = k;
         prev_slot = slot;
         slot ^= 1;
     }
-    if (prev && !drain(prev, prev_slot)) dl_fail(p, SF_ERR_HIP);
+    if (prev < np && !drain(prev, prev_slot)) dl_fail(p, SF_ERR_HIP);
 }
 
 int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     if (!p || !host_out || p->dl_active) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
     if (!p->h_ring) {
-        const size_t rb = (size_t)DL_WORKERS * 2 * DL_SLOT * sizeof(double);
+        const size_t rb = (size_t)p->dl_workers * 2 * p->dl_slot * sizeof(double);
         HIP_TRY(hipHostMalloc((void**)&p->h_ring, rb, hipHostMallocDefault));
         if (p->lu) {
             HIP_TRY(hipMalloc((void**)&p->d_ring, rb));
             p->bytes_device += rb;
         }
-        for (int w = 0; w < DL_WORKERS; ++w) {
+        for (int w = 0; w < p->dl_workers; ++w) {
             HIP_TRY(hipStreamCreateWithFlags(&p->dl_streams[w], hipStreamNonBlocking));
             for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&p->dl_done[w][k], hipEventDisableTiming));
         }
@@ -1038,7 +1053,12 @@ int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     p->dl_error.store(0);
     p->dl_active = true;
     p->dl_threads.clear();
-    const int nw = (int)std::min<size_t>(DL_WORKERS, p->dl_pieces.size());
+    // SF_DL_TRACE=path: per piece, the times (ms since the start of the download) at which its event was published, its DMA
+    // finished and its copy into the caller's buffer finished
+    p->dl_trace.clear();
+    if (getenv("SF_DL_TRACE")) p->dl_trace.assign(3 * p->dl_pieces.size(), 0.0);
+    p->dl_t0 = dl_now();
+    const int nw = (int)std::min<size_t>(p->dl_workers, p->dl_pieces.size());
     for (int w = 0; w < nw; ++w) p->dl_threads.emplace_back(dl_worker, p, w);
     return SF_OK;
 }
@@ -1054,6 +1074,15 @@ int sf_dl_end(sf_chol_plan* p) {
     p->dl_threads.clear();
     p->dl_active = false;
     p->dl_host = nullptr;
+    if (!p->dl_trace.empty()) {
+        if (FILE* f = fopen(getenv("SF_DL_TRACE") ? getenv("SF_DL_TRACE") : "/dev/null", "w")) {
+            fprintf(f, "piece,ready_launch,doubles,t_published_ms,t_dma_done_ms,t_copied_ms\n");
+            for (size_t k = 0; k < p->dl_pieces.size(); ++k)
+                fprintf(f, "%zu,%zu,%lld,%.3f,%.3f,%.3f\n", k, p->dl_pieces[k].ready, (long long)p->dl_pieces[k].count,
+                        p->dl_trace[3 * k], p->dl_trace[3 * k + 1], p->dl_trace[3 * k + 2]);
+            fclose(f);
+        }
+    }
     return p->dl_error.load();
 }
 

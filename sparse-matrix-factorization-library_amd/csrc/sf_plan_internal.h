@@ -68,8 +68,9 @@ static inline int upload(T** dptr, const std::vector<T>& h, size_t* bytes_total)
 // with compute on s_cudaStream_copyback, C:2888-2895).  A piece is a run of finished panel columns that is contiguous in
 // the host layout (and, for Cholesky, in the device layout), at most DL_SLOT doubles; it may be copied once launch
 // `ready` - 1 has completed (event `ev`).  Pieces are sorted by `ready`.
-constexpr int64_t DL_SLOT = (int64_t)4 << 20;      // doubles per staging slot (32 MiB)
-constexpr int DL_WORKERS = 6;                      // copy workers: own HIP stream + 2 pinned slots each
+constexpr int64_t DL_SLOT_DEFAULT = (int64_t)4 << 20;   // doubles per staging slot (32 MiB)
+constexpr int DL_WORKERS_DEFAULT = 6;                   // copy workers: own HIP stream + 2 pinned slots each
+constexpr int DL_WORKERS_MAX = 16;                      // SF_DL_WORKERS / SF_DL_SLOT_MB (read at plan creation) tune both
 struct DlPiece {
     int64_t dev_off, host_off, count;   // doubles; LU: dev_off unused (the piece is packed from the (L, U^T) panels)
     size_t ready;
@@ -87,12 +88,16 @@ struct sf_chol_plan {
     std::condition_variable dl_cv;
     size_t dl_published = 0;                    // events [0, dl_published) have been recorded (guarded by dl_mu)
     bool dl_abort = false;
-    double* h_ring = nullptr;                   // pinned staging ring: DL_WORKERS x 2 slots
+    double* h_ring = nullptr;                   // pinned staging ring: dl_workers x 2 slots of dl_slot doubles
     double* d_ring = nullptr;                   // LU: device staging of packed pieces, same shape
-    hipStream_t dl_streams[DL_WORKERS] = {};
-    hipEvent_t dl_done[DL_WORKERS][2] = {};
+    int64_t dl_slot = DL_SLOT_DEFAULT;
+    int dl_workers = DL_WORKERS_DEFAULT;
+    hipStream_t dl_streams[DL_WORKERS_MAX] = {};
+    hipEvent_t dl_done[DL_WORKERS_MAX][2] = {};
     double last_to_host_ms = 0;                 // wall time of the last sf_chol_plan_factorize_to_host
     std::vector<std::thread> dl_threads;
+    std::vector<double> dl_trace;               // SF_DL_TRACE: 3 times per piece
+    double dl_t0 = 0;
     std::atomic<int> dl_error{0};
     double* dl_host = nullptr;                  // destination of the running download (reference layout)
     bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
