@@ -950,8 +950,8 @@ int sf_chol_plan_factorize(sf_chol_plan* p, int sync) { return sf_chol_plan_fact
 
 // ---------------------------------------------------------------------------------------------------
 // Overlapped copy-back.  The reference copies finished blocks back on a second stream while it computes
-// (s_cudaStream_copyback, C:2888-2895).  Here: DL_WORKERS host threads, each with its own HIP stream and two pinned
-// 32 MiB staging slots.  Worker w takes pieces w, w + W, ... (pieces are sorted by the launch that finishes them): it
+// (s_cudaStream_copyback, C:2888-2895).  Here: a few host threads, each with its own HIP stream and two pinned
+// staging slots.  A worker pulls the next piece (pieces are sorted by the launch that finishes them): it
 // waits until the main thread has recorded the piece's event on the compute stream, makes its stream wait for that
 // event, starts the D2H into one slot and, while that DMA runs, copies the previous slot into the caller's buffer.
 // The caller's memory is never pinned or registered: fresh (never touched) pages of a just-malloc'ed Lsx are faulted in
@@ -995,7 +995,11 @@ static void dl_worker(sf_chol_plan* p, int w) {
         if (!p->dl_trace.empty()) p->dl_trace[3 * k + 2] = dl_now() - p->dl_t0;
         return true;
     };
-    for (size_t k = (size_t)w; k < np; k += W) {
+    // pieces are pulled from one shared counter, in ready order: streams do not all get the same share of the SDMA
+    // engines (measured: with a static round-robin split one worker of three finished at 570 ms, the others at 940 and
+    // 1070 ms), so the split has to be dynamic
+    (void)W;
+    for (size_t k = p->dl_next_piece.fetch_add(1); k < np; k = p->dl_next_piece.fetch_add(1)) {
         const DlPiece& pc = p->dl_pieces[k];
         {
             std::unique_lock<std::mutex> g(p->dl_mu);
@@ -1048,6 +1052,7 @@ int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     }
     p->dl_host = host_out;
     p->dl_next_ev = 0;
+    p->dl_next_piece.store(0);
     p->dl_published = 0;
     p->dl_abort = false;
     p->dl_error.store(0);

@@ -99,6 +99,7 @@ struct sf_chol_plan {
     std::vector<double> dl_trace;               // SF_DL_TRACE: 3 times per piece
     double dl_t0 = 0;
     std::atomic<int> dl_error{0};
+    std::atomic<size_t> dl_next_piece{0};
     double* dl_host = nullptr;                  // destination of the running download (reference layout)
     bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
     int64_t xC = 0;             // doubles in one set of nsrow x nscol panels (Cholesky: == xsize)

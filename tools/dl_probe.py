@@ -19,7 +19,7 @@ sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N, 3, 1), sf.REFERENCE_SLO
 host = np.zeros(sym.xsize)
 trace = os.path.join(ROOT, "gpurun_out", "dl_trace.csv")
 os.makedirs(os.path.dirname(trace), exist_ok=True)
-for workers, slot in ((6, 32), (12, 32), (6, 64), (12, 16), (3, 32)):
+for workers, slot in ((6, 32), (4, 64), (6, 64), (8, 64), (4, 128), (3, 32)):
     os.environ["SF_DL_WORKERS"], os.environ["SF_DL_SLOT_MB"] = str(workers), str(slot)
     plan = sf.CholPlan(sym, device=0)
     plan.set_values(sym.Lx)
