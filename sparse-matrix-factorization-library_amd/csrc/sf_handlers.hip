@@ -153,7 +153,10 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
     // one matrix = one handler; the caller's matrix threads (MATRIX_THREAD_NUM, C:3375) are spread over the devices
     struct gpu_info_struct& H = list[(serial >= 0 ? serial : 0) % common->numGPU];
     if (!H.st) return SF_ERR_NO_DEVICE;
+    const bool trace = getenv("SF_TRACE") != nullptr;      // stderr: where the time of this call goes
+    const auto tk0 = std::chrono::steady_clock::now();
     const PlanKey key = make_key(lu, n, nsuper, Super, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui);
+    const auto tk1 = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> guard(H.st->mu);
     HandlerState& S = *H.st;
     sf_chol_plan* plan = nullptr;
@@ -182,7 +185,15 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
         if (rc) return rc;
         S.cache.push_back(HandlerState::Entry{key, plan, ++S.clock});
     }
-    return sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
+    const auto tk2 = std::chrono::steady_clock::now();
+    const int rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
+    if (trace) {
+        const auto tk3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[sparseframe-hip] factorize: pattern hash %.1f ms, plan lookup/build %.1f ms, H2D + numeric + overlapped D2H %.1f ms\n",
+                ms(tk0, tk1), ms(tk1, tk2), ms(tk2, tk3));
+    }
+    return rc;
 }
 
 int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_allocate(common, list); }
