@@ -179,6 +179,23 @@ int sf_chol_plan_segment_pack(sf_chol_plan *plan, sf_long k, void **device_ptr, 
 int sf_chol_plan_factorize_segment(sf_chol_plan *plan, sf_long k, int sync);
 int sf_chol_plan_set_stream(sf_chol_plan *plan, void *hip_stream);
 
+/* ---- the parent-front merge in C: a communicator per rank, RCCL (= NCCL on ROCm, over xGMI) underneath,
+ * loaded at run time (librccl.so.1) so that single-GPU users do not need it.
+ *   one process per GPU:   rank 0 calls sf_comm_unique_id, hands the 128 bytes to the other ranks by any means (MPI,
+ *                          torch.distributed, a file), every rank calls sf_comm_create_rccl(&comm, device, rank, nranks, id)
+ *   one process, N GPUs:   SparseFrame_allocate_gpu / sf_handlers_allocate create the communicators themselves
+ * sf_chol_plan_factorize_distributed (Cholesky and LU plans): own subtrees, then per segment pack -> all-reduce(sum) ->
+ * chain + this rank's share of the split GEMMs, all on the plan's stream; host_out != NULL also copies this rank's pieces
+ * of the factor (own panels + its share of the top panels) into host_out while it computes. ---- */
+typedef struct sf_comm sf_comm;
+int sf_comm_unique_id(char *id128);
+int sf_comm_create_rccl(sf_comm **comm, int device, int rank, int nranks, const char *id128);
+int sf_comm_rank(const sf_comm *comm);
+int sf_comm_size(const sf_comm *comm);
+int sf_comm_allreduce_sum(sf_comm *comm, void *device_buf, sf_long count, void *hip_stream);
+int sf_comm_destroy(sf_comm *comm);
+int sf_chol_plan_factorize_distributed(sf_chol_plan *plan, sf_comm *comm, sf_float *host_out /* or NULL */, int sync);
+
 /* ---- device plan for supernodal no-pivot LU (replaces L:2668-3573 + LU/Source/cuda_kernel.cu:22-176).
  * Symbolic arrays from sf_symbolic_create_lu; Lsxp is the reference's (packed (2*nsrow-nscol) x nscol) offsets.
  * Up/Ui = U by row; pass NULL for both when the input is symmetric (U aliases L, L:2718-2729).

@@ -116,6 +116,18 @@ lib.sf_chol_plan_factorize_segment.argtypes = [C.c_void_p, C.c_int64, C.c_int]
 lib.sf_chol_plan_factorize_segment.restype = C.c_int
 lib.sf_chol_plan_set_stream.argtypes = [C.c_void_p, C.c_void_p]
 lib.sf_chol_plan_set_stream.restype = C.c_int
+lib.sf_comm_unique_id.argtypes = [C.c_char_p]
+lib.sf_comm_unique_id.restype = C.c_int
+lib.sf_comm_create_rccl.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char_p]
+lib.sf_comm_create_rccl.restype = C.c_int
+lib.sf_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+lib.sf_comm_allreduce_sum.restype = C.c_int
+lib.sf_comm_destroy.argtypes = [C.c_void_p]
+lib.sf_comm_destroy.restype = C.c_int
+lib.sf_comm_rank.argtypes = [C.c_void_p]
+lib.sf_comm_size.argtypes = [C.c_void_p]
+lib.sf_chol_plan_factorize_distributed.argtypes = [C.c_void_p, C.c_void_p, c_double_p, C.c_int]
+lib.sf_chol_plan_factorize_distributed.restype = C.c_int
 lib.sf_lu_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9
 lib.sf_lu_plan_create.restype = C.c_int
 lib.sf_lu_plan_create_distributed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9 + \

@@ -172,8 +172,41 @@ def phases_for_rank(owner, rank):
     return np.where(owner == rank, 0, np.where(owner < 0, 1, -1)).astype(np.int32)
 
 
+class Comm:
+    """one rank's RCCL communicator, created and used inside the C library (sf_comm_*): the unique id comes from rank 0
+    (`Comm.unique_id()`) and reaches the other ranks by whatever the launcher offers (torch.distributed here)"""
+
+    def __init__(self, device, rank, nranks, uid):
+        h = C.c_void_p()
+        check(lib.sf_comm_create_rccl(C.byref(h), device, rank, nranks, uid), "sf_comm_create_rccl")
+        self._h, self.rank, self.nranks = h, rank, nranks
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib.sf_comm_unique_id(buf), "sf_comm_unique_id")
+        return buf.raw
+
+    def allreduce_sum(self, device_ptr, count, stream=0):
+        check(lib.sf_comm_allreduce_sum(self._h, C.c_void_p(device_ptr), count, C.c_void_p(stream)), "sf_comm_allreduce_sum")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sf_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 class _ShardedPlanMixin:
     """multi-GPU entry points shared by CholPlan and LUPlan (one handle type in the C ABI)"""
+
+    def factorize_distributed(self, comm, host_out=None, sync=True):
+        """the whole sharded factorization from this rank's side, driven in C (sf_chol_plan_factorize_distributed): own
+        subtrees, then per segment pack -> RCCL all-reduce -> chain + this rank's share of the split GEMMs"""
+        out = _dp(host_out) if host_out is not None else None
+        check(lib.sf_chol_plan_factorize_distributed(self._h, comm._h, out, 1 if sync else 0), "sf_chol_plan_factorize_distributed")
 
     def factorize_phase(self, which, sync=True):
         check(lib.sf_chol_plan_factorize_phase(self._h, which, 1 if sync else 0), "sf_chol_plan_factorize_phase")

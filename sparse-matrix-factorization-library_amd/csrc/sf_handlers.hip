@@ -17,6 +17,9 @@
 #include <vector>
 
 #include "sf_plan_internal.h"
+#include "sf_symbolic.h"
+
+int sf_comm_create_all(sf_comm** comms, int nranks, const int* devices);     // sf_multi.hip
 
 namespace {
 
@@ -68,13 +71,30 @@ PlanKey make_key(int lu, sf_long n, sf_long nsuper, const sf_long* Super, const 
     return k;
 }
 
+// all handlers of a list working on ONE matrix (the reference runs numGPU + numCPU workers inside
+// SparseFrame_factorize_supernodal, C:2267): communicators and the per-rank distributed plans, hung off handler 0
+struct MultiState {
+    std::mutex mu;
+    std::vector<sf_comm*> comms;
+    struct Entry { PlanKey key; std::vector<sf_chol_plan*> plans; uint64_t stamp; };
+    std::vector<Entry> cache;
+    uint64_t clock = 0;
+    ~MultiState() {
+        for (Entry& e : cache)
+            for (sf_chol_plan* p : e.plans) sf_chol_plan_destroy(p);
+        for (sf_comm* c : comms) sf_comm_destroy(c);
+    }
+};
+
 struct HandlerState {
     std::mutex mu;
     struct Entry { PlanKey key; sf_chol_plan* plan; uint64_t stamp; };
     std::vector<Entry> cache;
     uint64_t clock = 0;
+    MultiState* multi = nullptr;        // handler 0 only
     ~HandlerState() {
         for (Entry& e : cache) sf_chol_plan_destroy(e.plan);
+        delete multi;
     }
 };
 constexpr size_t MAX_CACHED_PLANS = 2;      // per handler: MATRIX_THREAD_NUM = 2 matrices in flight in the reference's driver
@@ -87,13 +107,91 @@ struct gpu_info_struct {
     HandlerState* st;
 };
 
+// ONE factorization over all handlers of the list: rank r = handler r.  Every rank thread builds (or finds) its
+// distributed plan, uploads the values and runs sf_chol_plan_factorize_distributed with the overlapped copy-back of its
+// own pieces into Lsx_out (owned subtree panels; the top panels' pieces are dealt out over the ranks).
+static int factorize_all_handlers(struct common_info_struct* common, struct gpu_info_struct* list, int lu,
+                                  sf_long n, sf_long nsuper, const sf_long* Super, const sf_long* SuperMap,
+                                  const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                                  const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
+                                  const sf_float* Lx, const sf_float* Ux, sf_float* Lsx_out) {
+    const int N = common->numGPU;
+    MultiState& M = *list[0].st->multi;
+    PlanKey key = make_key(lu, n, nsuper, Super, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui);
+    key.h ^= 0x5bd1e995ull * (uint64_t)N;
+    std::lock_guard<std::mutex> guard(M.mu);
+    if (M.comms.empty()) {
+        std::vector<int> devs(N);
+        for (int r = 0; r < N; ++r) devs[r] = list[r].gpuIndex_physical;
+        M.comms.assign(N, nullptr);
+        const int rc = sf_comm_create_all(M.comms.data(), N, devs.data());
+        if (rc) { M.comms.clear(); return rc; }
+    }
+    MultiState::Entry* entry = nullptr;
+    for (MultiState::Entry& e : M.cache)
+        if (e.key == key) { entry = &e; e.stamp = ++M.clock; break; }
+    std::vector<int32_t> owner;
+    if (!entry) {
+        while (M.cache.size() >= MAX_CACHED_PLANS) {
+            size_t lru = 0;
+            for (size_t i = 1; i < M.cache.size(); ++i)
+                if (M.cache[i].stamp < M.cache[lru].stamp) lru = i;
+            for (sf_chol_plan* p : M.cache[lru].plans) sf_chol_plan_destroy(p);
+            M.cache.erase(M.cache.begin() + lru);
+        }
+        owner.assign(nsuper, 0);
+        // cost of a top flop relative to a subtree flop: its 1/N share plus the replicated chain and the all-reduce
+        if (sf::subtree_partition(nsuper, Super, SuperMap, Lsip, Lsi, N, owner.data(), nullptr, nullptr, 1.0 / N + 0.25)) return SF_ERR_ARG;
+        M.cache.push_back(MultiState::Entry{key, std::vector<sf_chol_plan*>(N, nullptr), ++M.clock});
+        entry = &M.cache.back();
+    }
+    std::vector<int> rcs(N, SF_OK);
+    std::vector<std::thread> th;
+    for (int r = 0; r < N; ++r)
+        th.emplace_back([&, r] {
+            int rc = SF_OK;
+            sf_chol_plan*& plan = entry->plans[r];
+            if (!plan) {
+                std::vector<int32_t> phase(nsuper);
+                for (sf_long s = 0; s < nsuper; ++s) phase[s] = owner[s] == r ? 0 : (owner[s] < 0 ? 1 : -1);
+                rc = lu ? sf_lu_plan_create_distributed(&plan, list[r].gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp,
+                                                        Lp, Li, Up, Ui, phase.data(), r == 0, r, N)
+                        : sf_chol_plan_create_distributed(&plan, list[r].gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp,
+                                                          Lp, Li, phase.data(), r == 0, r, N);
+            }
+            if (!rc) rc = lu ? sf_lu_plan_set_values(plan, Lx, Ux) : sf_chol_plan_set_values(plan, Lx);
+            // a rank without a usable plan cannot take part in the collectives; the others would wait for it, so plan
+            // creation is checked by all ranks before any of them starts (below)
+            rcs[r] = rc;
+        });
+    for (std::thread& t : th) t.join();
+    th.clear();
+    for (int r = 0; r < N; ++r)
+        if (rcs[r]) {
+            for (sf_chol_plan*& p : entry->plans) { sf_chol_plan_destroy(p); p = nullptr; }
+            M.cache.pop_back();
+            return rcs[r];
+        }
+    for (int r = 0; r < N; ++r)
+        th.emplace_back([&, r] { rcs[r] = sf_chol_plan_factorize_distributed(entry->plans[r], M.comms[r], Lsx_out, 1); });
+    for (std::thread& t : th) t.join();
+    for (int r = 0; r < N; ++r)
+        if (rcs[r]) return rcs[r];
+    return SF_OK;
+}
+
 extern "C" {
 
 int sf_handlers_allocate(struct common_info_struct* common, struct gpu_info_struct** list) {
     if (!common || !list) return 1;
     const auto t0 = std::chrono::steady_clock::now();
-    int ndev = sf_device_count();
-    common->numGPU_physical = ndev;
+    const int nphys = sf_device_count();
+    int ndev = nphys;
+    // SF_EMULATE_HANDLERS=N on a one-GPU box: N handlers that share device 0 (the multi-handler code path end to end,
+    // with the all-reduce done by a kernel on that device instead of RCCL) -- tests and rehearsals only
+    if (nphys == 1)
+        if (const char* env = getenv("SF_EMULATE_HANDLERS")) ndev = std::max(1, std::min(16, atoi(env)));
+    common->numGPU_physical = nphys;
     common->numGPU = ndev;       // one handler per device; no virtual-GPU splitting (reference C:36-41)
     common->numCPU = 0;          // the numeric phase has no CPU worker
     common->minDevMemSize = 0;
@@ -103,12 +201,14 @@ int sf_handlers_allocate(struct common_info_struct* common, struct gpu_info_stru
     size_t min_mem = (size_t)-1;
     for (int d = 0; d < ndev; ++d) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
-        (*list)[d].gpuIndex_physical = d;
+        const int phys = nphys == 1 ? 0 : d;
+        if (hipGetDeviceProperties(&prop, phys) != hipSuccess) continue;
+        (*list)[d].gpuIndex_physical = phys;
         (*list)[d].devMemSize = prop.totalGlobalMem;
         (*list)[d].st = new (std::nothrow) HandlerState();
         min_mem = std::min(min_mem, (size_t)prop.totalGlobalMem);
     }
+    if (ndev > 0 && (*list)[0].st) (*list)[0].st->multi = new (std::nothrow) MultiState();
     if (ndev > 0 && min_mem != (size_t)-1) {
         common->devSlotSize = sf_reference_slot_size(ndev, min_mem);
         common->minDevMemSize = common->devSlotSize * 8;
@@ -150,6 +250,13 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
         return SF_ERR_NO_DEVICE;
     }
     if (n > 0 && (!SuperMap || !Lsi || !Li)) return SF_ERR_ARG;
+    // Several handlers: all of them factorize this matrix together, as in the reference (C:2267) -- elimination-tree
+    // subtrees per handler, RCCL for the parent-front merge.  SF_MULTI=matrix keeps one matrix per handler instead.
+    if (common->numGPU > 1 && nsuper > 0 && list[0].st && list[0].st->multi) {
+        const char* mode = getenv("SF_MULTI");
+        if (!mode || strcmp(mode, "matrix") != 0)
+            return factorize_all_handlers(common, list, lu, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, Lx, Ux, Lsx_out);
+    }
     // one matrix = one handler; the caller's matrix threads (MATRIX_THREAD_NUM, C:3375) are spread over the devices
     struct gpu_info_struct& H = list[(serial >= 0 ? serial : 0) % common->numGPU];
     if (!H.st) return SF_ERR_NO_DEVICE;

@@ -1,0 +1,301 @@
+// Multi-GPU orchestration inside the library: the parent-front merge of a sharded factorization as RCCL
+// collectives on the plan's own stream, driven from C.
+//
+//   sf_comm                 one rank's end of a group of `nranks` plans that factorize ONE matrix together
+//     kind RCCL             ncclComm_t (RCCL = the ROCm build of NCCL, over xGMI inside a node).  librccl.so.1 is loaded at run
+//                           time with dlopen, so a single-GPU user never needs it and a process that already loaded a copy
+//                           (PyTorch bundles one) shares that copy.
+//     kind LOCAL            ranks are threads of this process whose plans live on ONE device (emulated ranks: tests and
+//                           rehearsals on a one-GPU box): event hand-shakes + a sum kernel on that device.  Same call sites
+//                           and ordering as the RCCL kind; never used when the ranks have devices of their own.
+//   sf_chol_plan_factorize_distributed   phase 0 (own subtrees), then per segment: pack -> all-reduce(sum) -> chain +
+//                           this rank's share of the split GEMMs (sf_chol_plan.hip), all enqueued on the plan's stream with
+//                           no host synchronisation; optionally with the overlapped copy-back of this rank's pieces.
+//
+// The reference has no inter-GPU path: its device handlers exchange panels through pinned host memory under one task
+// queue (Cholesky/Source/SparseFrame.c:2267, 2421-2467).
+#include <sparseframe_hip.h>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "sf_plan_internal.h"
+
+namespace {
+
+// ---- RCCL entry points, resolved once ----
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) {
+            fprintf(stderr, "[sparseframe-hip] cannot load librccl.so.1 (%s): multi-GPU factorization is unavailable\n", dlerror());
+            return;
+        }
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+        api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.handle, "ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.AllReduce && api.GetErrorString;
+        if (!api.ok) fprintf(stderr, "[sparseframe-hip] librccl.so.1 lacks an expected entry point\n");
+    });
+    return api;
+}
+
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess) {                                                                                \
+            fprintf(stderr, "[sparseframe-hip] %s failed: %s (%s:%d)\n", #expr, rccl().GetErrorString(r_), __FILE__, __LINE__); \
+            return SF_ERR_HIP;                                                                                  \
+        }                                                                                                       \
+    } while (0)
+
+// ---- LOCAL kind: threads of one process, one device ----
+constexpr int LOCAL_MAX = 16;
+struct LocalGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    double* bufs[LOCAL_MAX] = {};
+    int64_t counts[LOCAL_MAX] = {};
+    hipEvent_t ev_ready[LOCAL_MAX] = {}, ev_done[LOCAL_MAX] = {};
+    hipEvent_t ev_sum = nullptr;
+    int refs = 0;
+    bool failed = false;
+    void barrier() {
+        std::unique_lock<std::mutex> g(mu);
+        const uint64_t gen = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(g, [&] { return generation != gen; });
+    }
+};
+
+struct PtrTable { const double* p[LOCAL_MAX]; };
+
+__global__ void __launch_bounds__(256)
+k_sum_ranks(double* __restrict__ dst, PtrTable src, int nsrc, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = dst[i];
+        for (int q = 0; q < nsrc; ++q) v += src.p[q][i];
+        dst[i] = v;
+    }
+}
+
+}  // namespace
+
+struct sf_comm {
+    int kind = 0;       // 0 RCCL, 1 LOCAL
+    int rank = 0, nranks = 1;
+    int device = 0;
+    ncclComm_t nccl = nullptr;
+    LocalGroup* local = nullptr;
+};
+
+namespace {
+
+int local_allreduce(sf_comm* c, double* buf, int64_t count, hipStream_t st) {
+    LocalGroup& G = *c->local;
+    const int r = c->rank, n = G.n;
+    G.bufs[r] = buf;
+    G.counts[r] = count;
+    // count < 0: this rank has failed and only keeps the hand-shake going so that the others do not wait for ever
+    bool ok = count >= 0 && hipEventRecord(G.ev_ready[r], st) == hipSuccess;
+    if (!ok) { std::lock_guard<std::mutex> g(G.mu); G.failed = true; }
+    G.barrier();
+    { std::lock_guard<std::mutex> g(G.mu); ok = ok && !G.failed; }
+    if (r == 0) {
+        for (int q = 1; q < n && ok; ++q) {
+            ok = ok && G.counts[q] == count;        // every rank reduces the same segment
+            ok = ok && hipStreamWaitEvent(st, G.ev_ready[q], 0) == hipSuccess;
+        }
+        if (ok && count > 0) {
+            PtrTable t{};
+            for (int q = 1; q < n; ++q) t.p[q - 1] = G.bufs[q];
+            const int64_t blocks = std::min<int64_t>((count + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_sum_ranks, dim3((unsigned)blocks), dim3(256), 0, st, buf, t, n - 1, count);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        ok = ok && hipEventRecord(G.ev_sum, st) == hipSuccess;
+    }
+    G.barrier();
+    if (r > 0) {
+        ok = ok && hipStreamWaitEvent(st, G.ev_sum, 0) == hipSuccess;
+        if (ok && count > 0) ok = hipMemcpyAsync(buf, G.bufs[0], (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, st) == hipSuccess;
+        ok = ok && hipEventRecord(G.ev_done[r], st) == hipSuccess;
+    }
+    if (!ok) { std::lock_guard<std::mutex> g(G.mu); G.failed = true; }
+    G.barrier();
+    if (r == 0)
+        for (int q = 1; q < n; ++q) ok = ok && hipStreamWaitEvent(st, G.ev_done[q], 0) == hipSuccess;
+    bool failed;
+    { std::lock_guard<std::mutex> g(G.mu); failed = G.failed; }
+    return (ok && !failed) ? SF_OK : SF_ERR_HIP;
+}
+
+}  // namespace
+
+// used by the handlers (sf_handlers.hip): communicators of all ranks of one process at once
+int sf_comm_create_all(sf_comm** comms, int nranks, const int* devices) {
+    if (!comms || nranks < 1 || nranks > LOCAL_MAX || !devices) return SF_ERR_ARG;
+    bool same_device = nranks > 1;
+    bool distinct = true;
+    for (int a = 0; a < nranks; ++a)
+        for (int b = a + 1; b < nranks; ++b) {
+            if (devices[a] != devices[b]) same_device = false; else distinct = false;
+        }
+    for (int r = 0; r < nranks; ++r) comms[r] = nullptr;
+    if (nranks > 1 && !same_device && !distinct) return SF_ERR_ARG;     // a mix of shared and own devices is not supported
+    if (same_device) {
+        LocalGroup* G = new (std::nothrow) LocalGroup();
+        if (!G) return SF_ERR_ALLOC;
+        G->n = nranks;
+        G->refs = nranks;
+        HIP_TRY(hipSetDevice(devices[0]));
+        bool ok = hipEventCreateWithFlags(&G->ev_sum, hipEventDisableTiming) == hipSuccess;
+        for (int r = 0; r < nranks; ++r) {
+            ok = ok && hipEventCreateWithFlags(&G->ev_ready[r], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&G->ev_done[r], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) { delete G; return SF_ERR_HIP; }
+        for (int r = 0; r < nranks; ++r) {
+            comms[r] = new sf_comm();
+            comms[r]->kind = 1; comms[r]->rank = r; comms[r]->nranks = nranks; comms[r]->device = devices[0]; comms[r]->local = G;
+        }
+        return SF_OK;
+    }
+    if (!rccl().ok) return SF_ERR_NO_DEVICE;
+    std::vector<ncclComm_t> nc(nranks, nullptr);
+    NCCL_TRY(rccl().CommInitAll(nc.data(), nranks, devices));
+    for (int r = 0; r < nranks; ++r) {
+        comms[r] = new sf_comm();
+        comms[r]->kind = 0; comms[r]->rank = r; comms[r]->nranks = nranks; comms[r]->device = devices[r]; comms[r]->nccl = nc[r];
+    }
+    return SF_OK;
+}
+
+extern "C" {
+
+int sf_comm_unique_id(char* id128) {
+    if (!id128) return SF_ERR_ARG;
+    if (!rccl().ok) return SF_ERR_NO_DEVICE;
+    ncclUniqueId id;
+    NCCL_TRY(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id.internal) == 128, "unique id is 128 bytes");
+    memcpy(id128, id.internal, 128);
+    return SF_OK;
+}
+
+int sf_comm_create_rccl(sf_comm** out, int device, int rank, int nranks, const char* id128) {
+    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return SF_ERR_ARG;
+    *out = nullptr;
+    if (!rccl().ok) return SF_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, 128);
+    ncclComm_t nc = nullptr;
+    NCCL_TRY(rccl().CommInitRank(&nc, nranks, id, rank));
+    sf_comm* c = new (std::nothrow) sf_comm();
+    if (!c) return SF_ERR_ALLOC;
+    c->kind = 0; c->rank = rank; c->nranks = nranks; c->device = device; c->nccl = nc;
+    *out = c;
+    return SF_OK;
+}
+
+int sf_comm_rank(const sf_comm* c) { return c ? c->rank : -1; }
+int sf_comm_size(const sf_comm* c) { return c ? c->nranks : 0; }
+
+int sf_comm_destroy(sf_comm* c) {
+    if (!c) return SF_OK;
+    if (c->kind == 0 && c->nccl) (void)rccl().CommDestroy(c->nccl);
+    if (c->kind == 1 && c->local) {
+        LocalGroup* G = c->local;
+        bool last;
+        { std::lock_guard<std::mutex> g(G->mu); last = --G->refs == 0; }
+        if (last) {
+            (void)hipSetDevice(c->device);
+            if (G->ev_sum) (void)hipEventDestroy(G->ev_sum);
+            for (int r = 0; r < G->n; ++r) {
+                if (G->ev_ready[r]) (void)hipEventDestroy(G->ev_ready[r]);
+                if (G->ev_done[r]) (void)hipEventDestroy(G->ev_done[r]);
+            }
+            delete G;
+        }
+    }
+    delete c;
+    return SF_OK;
+}
+
+// sum `count` doubles at `device_buf` over the ranks, in place, ordered on `stream` (no host synchronisation)
+int sf_comm_allreduce_sum(sf_comm* c, void* device_buf, sf_long count, void* stream) {
+    if (!c || (count > 0 && !device_buf)) return SF_ERR_ARG;
+    if (count < 0 && c->kind != 1) return SF_ERR_ARG;
+    if (c->kind == 1) return c->nranks == 1 ? SF_OK : local_allreduce(c, (double*)device_buf, count, (hipStream_t)stream);
+    if (count == 0) return SF_OK;
+    NCCL_TRY(rccl().AllReduce(device_buf, device_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, (hipStream_t)stream));
+    return SF_OK;
+}
+
+// One sharded factorization from this rank's point of view (plan from sf_chol_plan_create_distributed /
+// sf_lu_plan_create_distributed with the same rank / nranks as `comm`): own subtrees, then for every segment the
+// parent-front merge (one all-reduce of the packed block columns) and the segment's launches.  host_out != NULL: the
+// pieces of the factor this rank is responsible for are copied into it while the factorization runs.
+int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float* host_out, int sync) {
+    if (!p || !comm || comm->nranks != p->nranks || comm->rank != p->rank) return SF_ERR_ARG;
+    if (p->nranks == 1) {
+        if (host_out) return SF_ERR_ARG;        // single rank: sf_chol_plan_factorize_to_host
+        return sf_chol_plan_factorize(p, sync);
+    }
+    int rc = SF_OK;
+    if (host_out && (rc = sf_dl_begin(p, host_out))) return rc;
+    rc = sf_chol_plan_factorize_phase(p, 0, 0);
+    const sf_long nseg = sf_chol_plan_num_segments(p);
+    for (sf_long k = 0; k < nseg; ++k) {
+        if (rc) {
+            // emulated ranks hand-shake on the host: a failed rank keeps taking part so that the others return too
+            if (comm->kind == 1) (void)sf_comm_allreduce_sum(comm, nullptr, -1, (void*)p->stream);
+            continue;
+        }
+        void* buf = nullptr;
+        sf_long cnt = 0;
+        rc = sf_chol_plan_segment_pack(p, k, &buf, &cnt);
+        if (rc) { --k; continue; }      // re-enter the loop for this segment in the failed state
+        rc = sf_comm_allreduce_sum(comm, buf, cnt, (void*)p->stream);
+        if (!rc) rc = sf_chol_plan_factorize_segment(p, k, 0);
+    }
+    int rc_dl = SF_OK;
+    if (host_out) rc_dl = sf_dl_end(p);         // (also releases the copy workers when rc != 0)
+    if (rc) return rc;
+    if (sync || host_out) {
+        const int rs = sf_chol_plan_sync(p);
+        return rs ? rs : rc_dl;
+    }
+    return SF_OK;
+}
+
+}  // extern "C"

@@ -77,6 +77,8 @@ struct DlPiece {
     int ev;
 };
 
+struct sf_comm;      // one rank's end of a multi-GPU group (sf_multi.hip)
+
 struct sf_chol_plan {
     // ---- overlapped download schedule (built once) and the state of a running download ----
     std::vector<DlPiece> dl_pieces;

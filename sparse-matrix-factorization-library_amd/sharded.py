@@ -37,7 +37,7 @@ class _DevArray:
 
 
 class HipEngine:
-    def __init__(self, sym, phase, load_top, device, rank=0, world=1, distributed=False):
+    def __init__(self, sym, phase, load_top, device, rank=0, world=1, distributed=False, group=None):
         self.distributed = bool(distributed and world > 1)
         self.lu = bool(getattr(sym, "lu", False))
         if self.lu and world > 1 and not self.distributed:
@@ -51,10 +51,22 @@ class HipEngine:
         self.device = device
         self._top = None
         self._seg = {}
+        self.comm = None
         if self.distributed:
-            # run on the stream the collectives are ordered with: segments and all-reduces alternate without host syncs
             import torch
-            self.plan.set_stream(torch.cuda.current_stream(device).cuda_stream)
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_backend(group) == "nccl":
+                # the product path: the collectives are issued by the C library itself (RCCL on the plan's stream,
+                # sf_chol_plan_factorize_distributed); torch.distributed only carries the 128-byte unique id
+                from .api import Comm
+                uid = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{device}")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0, group=group)
+                self.comm = Comm(device, rank, world, bytes(uid.cpu().numpy().tobytes()))
+            else:
+                # rehearsals (gloo: several ranks on one GPU): the collective is torch's, so run on the stream it is ordered with
+                self.plan.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def set_values(self, Lx, Ux=None):
         if self.lu:
@@ -101,7 +113,12 @@ class HipEngine:
     def get_factor(self, out=None):
         return self.plan.get_factor(out)
 
+    def factorize_distributed(self):
+        self.plan.factorize_distributed(self.comm, sync=False)
+
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
         self.plan.close()
 
 
@@ -115,7 +132,7 @@ class ShardedFactorization:
         self.owner, self.top_fraction, self.max_load_fraction = subtree_partition(sym, world, self.top_weight)
         phase = phases_for_rank(self.owner, rank)
         dist_mode = self.mode == "distributed"
-        factory = engine_factory or (lambda s, ph, lt, r, w, d: HipEngine(s, ph, lt, device, r, w, d))
+        factory = engine_factory or (lambda s, ph, lt, r, w, d: HipEngine(s, ph, lt, device, r, w, d, group))
         self.engine = factory(sym, phase, rank == 0, rank, world, dist_mode)
         self.phase = phase
 
@@ -139,6 +156,10 @@ class ShardedFactorization:
         import torch.distributed as dist
         eng = self.engine
         eng.factorize_phase(0)
+        if self.mode == "distributed" and getattr(eng, "comm", None) is not None:
+            eng.factorize_distributed()         # C driver + RCCL; asynchronous, finish() waits
+            eng.finish()
+            return
         if self.mode == "distributed":
             for k in range(eng.num_segments()):
                 for t in eng.segment_tensors(k):

@@ -1,0 +1,113 @@
+"""Multi-GPU through the reference's own C entry point: SparseFrame_factorize_supernodal uses EVERY handler of
+gpu_info_list for one matrix (reference C:2267): elimination-tree subtrees per handler, the parent-front merge as a
+collective issued by the C library on the plans' streams (sf_multi.hip).
+
+On a one-GPU box SF_EMULATE_HANDLERS=N makes SparseFrame_allocate_gpu return N handlers that share device 0; the
+orchestration, the per-rank distributed plans, the segment loop and the dealt-out overlapped copy-back are the real
+ones, only the all-reduce is a kernel on that device instead of RCCL.  With >= 2 devices the same test body runs over
+RCCL.  The RCCL binding itself (dlopen, unique id, communicator, ncclAllReduce on a caller's stream) is exercised
+with a one-rank communicator."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import sf, gen, nd_perm_py, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL_FACTOR = 1e-12
+TOL_RESIDUAL = 1e-13
+
+
+def _chol_case(oracle, N, nhandlers_expected):
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    perm = sf.grid_nd_perm(N, N, N)
+    common = sf.CommonInfo(dev_slot_size=8 << 30)
+    assert common.c.numGPU == nhandlers_expected
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, 8 << 30)
+    ref, info, _ = oracle.chol_factorize(sym)
+    mask = oracle.lower_mask(sym)
+    for scale in (1.0, 2.0):            # second call: cached per-rank plans and communicators
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx * scale)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        C.memset(mi.c.Lsx, 0xff, 8 * sym.xsize)          # NaNs: every entry must be written by some rank's copy-back
+        mi.factorize(common)
+        got = mi.array("Lsx", sym.xsize).copy()
+        assert not np.isnan(got[mask]).any()
+        assert rel_err(got, ref * np.sqrt(scale), mask) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    common.close()
+
+
+@pytest.mark.parametrize("nh", [2, 3, 8])
+def test_all_handlers_factorize_one_matrix_emulated(oracle, monkeypatch, nh):
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", str(nh))
+    _chol_case(oracle, 24, nh)
+
+
+def test_all_handlers_lu_emulated(oracle, monkeypatch):
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", "2")
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(12, 12, 12, seed=3)
+    perm = nd_perm_py(12, 12, 12)
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    assert common.c.numGPU == 2
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    mi.factorize(common)
+    assert mi.validate() <= TOL_RESIDUAL
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    ref, info, _ = oracle.lu_factorize(S)
+    assert rel_err(mi.array("Lsx", S.xsize).copy(), ref) <= TOL_FACTOR
+    mi.cleanup()
+    common.close()
+
+
+def test_one_matrix_per_handler_mode(oracle, monkeypatch):
+    """SF_MULTI=matrix: the matrices of the caller's matrix threads are spread over the handlers instead"""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", "2")
+    monkeypatch.setenv("SF_MULTI", "matrix")
+    n, Cp, Ci, Cx = gen.laplacian_lower(12, 12, 12)
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    for serial in (0, 1):
+        mi = sf.MatrixInfo(serial=serial)
+        mi.set_csc(n, Cp, Ci, Cx)
+        mi.analyze(common)
+        mi.factorize(common)
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    common.close()
+
+
+def test_two_device_handlers_over_rccl(oracle):
+    """the real thing: needs >= 2 MI355X in this process (skips on the one-GPU test boxes)"""
+    if sf.device_count() < 2:
+        pytest.skip("needs two devices")
+    _chol_case(oracle, 24, sf.device_count())
+
+
+def test_rccl_binding_one_rank_communicator():
+    """librccl.so.1 through the library's own binding: unique id, ncclCommInitRank, ncclAllReduce(sum, fp64) on the caller's
+    stream, destroy.  One rank: the sum is the input."""
+    import torch
+    uid = sf.Comm.unique_id()
+    assert len(uid) == 128
+    comm = sf.Comm(0, 0, 1, uid)
+    t = torch.arange(1 << 20, dtype=torch.float64, device="cuda:0")
+    want = t.clone()
+    s = torch.cuda.Stream(device=0)
+    s.wait_stream(torch.cuda.current_stream(0))
+    comm.allreduce_sum(t.data_ptr(), t.numel(), s.cuda_stream)
+    s.synchronize()
+    assert torch.equal(t, want)
+    comm.close()
