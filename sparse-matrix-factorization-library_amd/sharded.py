@@ -55,7 +55,7 @@ class HipEngine:
         if self.distributed:
             import torch
             import torch.distributed as dist
-            if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            if dist.is_initialized() and dist.get_backend(group) == "nccl" and dist.get_world_size(group) == world:
                 # the product path: the collectives are issued by the C library itself (RCCL on the plan's stream,
                 # sf_chol_plan_factorize_distributed); torch.distributed only carries the 128-byte unique id
                 from .api import Comm
