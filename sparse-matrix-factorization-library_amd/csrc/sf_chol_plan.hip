@@ -61,7 +61,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_x, p->d_relmap, p->d_scratch};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -316,6 +316,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             // then its diagonal block is factored and the rows below are solved.  (A right-looking trailing
             // update would read-modify-write the rest of the outer block at every step with K = 64.)
             const int ninner = sf::OUTER_NB / sf::NB;
+            bool block_fused = false;       // decided at the block's first step (the largest), kept for all its steps: the
+                                            // fused Cholesky steps push updates into the block's FUTURE diagonal blocks
             for (int ti = 0; ti < ninner; ++ti) {
                 const int diag = J + ti * sf::NB;
                 if (diag >= maxcol) break;
@@ -324,7 +326,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
                     if (diag < nscol) step_wgs += 1 + (lu ? 2 : 1) * ((nsrow - std::min<int64_t>(nscol, diag + sf::NB) + sf::ST_ROWS - 1) / sf::ST_ROWS);
                 }
-                if (step_wgs <= fuse_max) {
+                if (ti == 0) block_fused = step_wgs <= fuse_max;
+                if (block_fused) {
                     // latency-bound step: the (update, POTRF / GETRF, TRSM) triple is ONE launch of k_step.  Steps with
                     // more tiles are throughput-bound and keep the three launches (stream-K GEMM over all tiles,
                     // 256-row TRSM workgroups).
@@ -335,7 +338,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         if (diag >= nscol) { flag_of.push_back(-1); slot_of.push_back(-1); continue; }
                         const int b = std::min(sf::NB, nscol - diag);
                         flag_of.push_back(n_flags);
-                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, J, diag, b, diag, b, n_flags++, 0, (int32_t)(steps.size() - d0), 0});
+                        // Cholesky: J = diag (no left-looking update): the diagonal block arrives up to date, see k_step
+                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, lu ? J : diag, diag, b, diag, b, n_flags++, 0, (int32_t)(steps.size() - d0), 0});
                         slot_of.push_back((int32_t)(steps.size() - 1 - d0));
                         if (ti > 0) p->flops_panel_gemm += (lu ? 2.0 : 1.0) * ((double)b * (b + 1) * (diag - J) + 2.0 * (nsrow - diag - b) * (double)b * (diag - J));
                     }
@@ -349,7 +353,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         for (int r = diag + b; r < nsrow; r += sf::ST_ROWS) {
                             const int nr = std::min(sf::ST_ROWS, nsrow - r);
                             if (!lu) {
-                                steps.push_back(StepTask{XP[s], XP[s], nsrow, J, diag, b, r, nr, fl, 0, sl, 0});
+                                // rows that are a later diagonal block of this outer block get this step's X X^T pushed into them
+                                const int nb = (r < std::min(nscol, J + sf::OUTER_NB)) ? std::min(sf::NB, nscol - r) : 0;
+                                steps.push_back(StepTask{XP[s], XP[s], nsrow, J, diag, b, r, nr, fl, 0, sl, nb});
                             } else {
                                 steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, diag, b, r, nr, fl, 0, sl, 0});     // L21 <- (L21 - ..) U11^{-1}
                                 steps.push_back(StepTask{XP[s] + ushift, XP[s], nsrow, J, diag, b, r, nr, fl, 1, sl, 0});     // U12^T <- (U12^T - ..) L11^{-T}
@@ -475,39 +481,42 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     p->n_gemm_tasks = (int64_t)gtasks.size() + (int64_t)stasks.size();
 
     // ---------------- device solve schedule (unsharded plans) ----------------
+    // per (level, 64-column step): a forward launch [diagonal tasks, 256-row tiles] and a backward launch [tiles, diagonal tasks]
     std::vector<sf::SolveTask> solve;
+    int32_t n_solve_sync = 0;
     if (!p->partial) {
         std::vector<std::vector<sf_long>> by_level(nlevels);
         for (sf_long s = 0; s < nsuper; ++s) by_level[level[s]].push_back(s);
+        const int tile = 256;
         for (int l = 0; l < nlevels; ++l) {
             sf_long maxcol = 0;
             for (sf_long s : by_level[l]) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
             for (int diag = 0; diag < maxcol; diag += sf::NB) {
                 sf_chol_plan::SolveStep st{};
-                st.diag_first = (int64_t)solve.size();
+                std::vector<sf::SolveTask> dg, rows;
                 for (sf_long s : by_level[l]) {
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
                     if (diag >= nscol) continue;
-                    solve.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, std::min(sf::NB, nscol - diag), 0, 0, (int32_t)Super[s]});
+                    const int b = std::min(sf::NB, nscol - diag);
+                    const int ntiles = (nsrow - diag - b + tile - 1) / tile;
+                    // sync words: [flag] forward "solved" flag, [flag + 1] backward tile counter
+                    dg.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, b, 0, 0, (int32_t)Super[s], n_solve_sync, ntiles});
+                    for (int r = diag + b; r < nsrow; r += tile)
+                        rows.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, b, r, std::min(tile, nsrow - r), (int32_t)Super[s], n_solve_sync, 0});
+                    n_solve_sync += 2;
                 }
-                st.diag_count = (int)(solve.size() - st.diag_first);
-                for (int dir = 0; dir < 2; ++dir) {         // 0: forward, 1: backward; tiles of 256 rows
-                    const int tile = 256;
-                    const int64_t first = (int64_t)solve.size();
-                    for (sf_long s : by_level[l]) {
-                        const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
-                        if (diag >= nscol) continue;
-                        const int b = std::min(sf::NB, nscol - diag);
-                        for (int r = diag + b; r < nsrow; r += tile)
-                            solve.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, b, r, std::min(tile, nsrow - r), (int32_t)Super[s]});
-                    }
-                    if (dir) { st.bwd_first = first; st.bwd_count = (int)(solve.size() - first); }
-                    else { st.fwd_first = first; st.fwd_count = (int)(solve.size() - first); }
-                }
+                st.fwd_first = (int64_t)solve.size();
+                solve.insert(solve.end(), dg.begin(), dg.end());
+                solve.insert(solve.end(), rows.begin(), rows.end());
+                st.bwd_first = (int64_t)solve.size();
+                for (sf::SolveTask t : rows) { t.flag += 1; solve.push_back(t); }
+                for (sf::SolveTask t : dg) { t.flag += 1; solve.push_back(t); }
+                st.count = (int)(dg.size() + rows.size());
                 p->solve_steps.push_back(st);
             }
         }
     }
+    p->n_solve_sync = n_solve_sync;
 
     // K-step prefix of every GEMM launch (stream-K work distribution, see k_gemm)
     std::vector<uint32_t> ktprefix;
@@ -640,6 +649,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         if (!solve.empty()) {
             if ((rc = upload(&p->d_solve, solve, &p->bytes_device))) break;
+            // sync words of the solve: [0] status, then the flags / counters, then two launch tickets per step
+            const size_t sb = (size_t)(1 + p->n_solve_sync + 2 * p->solve_steps.size()) * sizeof(int);
+            if (hipMalloc((void**)&p->d_solve_sync, sb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += sb;
             if (hipMalloc((void**)&p->d_x, std::max<int64_t>(n, 1) * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += std::max<int64_t>(n, 1) * sizeof(double);
         }
@@ -1220,19 +1233,26 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     // created here, so an error return leaks nothing
     hipEvent_t e0 = p->ev_s0, e1 = p->ev_s1;
     HIP_TRY(hipEventRecord(e0, st));
-    for (const auto& s : p->solve_steps) {
-        sf::launch_solve_fwd_diag(p->d_solve + s.diag_first, s.diag_count, fwd_base, p->d_x, st, p->lu ? 1 : 0);
-        sf::launch_solve_fwd_update(p->d_solve + s.fwd_first, s.fwd_count, fwd_base, p->d_Lsi, p->d_x, st);
-    }
-    for (size_t k = p->solve_steps.size(); k-- > 0;) {
+    const size_t nst = p->solve_steps.size();
+    int* sync = p->d_solve_sync + 1;
+    int* tickets = sync + p->n_solve_sync;
+    HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + 2 * nst) * sizeof(int), st));
+    for (size_t k = 0; k < nst; ++k) {
         const auto& s = p->solve_steps[k];
-        sf::launch_solve_bwd_update(p->d_solve + s.bwd_first, s.bwd_count, bwd_base, p->d_Lsi, p->d_x, st);
-        sf::launch_solve_bwd_diag(p->d_solve + s.diag_first, s.diag_count, bwd_base, p->d_x, st);
+        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.count, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0, sync, tickets + 2 * k,
+                             p->d_solve_sync, st);
+    }
+    for (size_t k = nst; k-- > 0;) {
+        const auto& s = p->solve_steps[k];
+        sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 2 * k + 1, p->d_solve_sync, st);
     }
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(x_host, p->d_x, p->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    int sinfo = 0;
+    HIP_TRY(hipMemcpyAsync(&sinfo, p->d_solve_sync, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (sinfo) return SF_ERR_HIP;       // a bounded in-launch wait ran out (never seen)
     float ms = 0;
     if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) p->last_solve_ms = ms;
     return SF_OK;

@@ -66,12 +66,14 @@ struct StepTask {   // fused 64-column step on rows [row0, row0+nrows) of panel 
     int64_t panel;          // panel of the tile (and of its own rows' operand)
     int64_t xpanel;         // panel of the other operand = the diagonal block's rows, and of the triangular block the rows are
                             // solved against (Cholesky: == panel; LU: the U^T panel for L rows and vice versa)
-    int32_t ld, J, diag, b;
+    int32_t ld, J, diag, b; // J: first column of the left-looking update (Cholesky diagonal tasks: J == diag, their block is kept
+                            // up to date right-looking by the row tasks' pushes, see next_b)
     int32_t row0, nrows;    // row0 == diag: the diagonal block (POTRF / GETRF, publishes `flag`); else rows below it (wait for `flag`)
     int32_t flag;           // index of this (panel, step)'s flag
     int32_t mode;           // bit 0: the triangular block has an implicit unit diagonal (LU: U12^T <- U12^T L11^{-T})
     int32_t slot;           // index (within the launch) of the diagonal task whose 16 x 16 inverses the rows use
-    int32_t pad;
+    int32_t next_b;         // row task, Cholesky: > 0 = these rows are a future diagonal block of the outer block, next_b wide:
+                            // push X X^T into it
 };
 
 // skip_diag != 0: entries with row == column are not stored (LU: the L panel)
@@ -108,17 +110,22 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
 void launch_update_small(const GemmProb* probs, const GemmTask* tasks, int ntasks, double* Lsx, const int32_t* RelMap, hipStream_t st);
 
 // ---- device-side supernodal triangular solves with the resident factor (reference: scalar host loops,
-// Cholesky/Source/SparseFrame.c:3074-3134).  64-column block steps, the same (level, step) sweep as the factorization.
+// Cholesky/Source/SparseFrame.c:3074-3134).  64-column block steps, the same (level, step) sweep as the factorization;
+// one launch per step and direction, the diagonal solve and the row tiles hand over inside the launch.
 struct SolveTask {
     int64_t panel;      // doubles, into Lsx
     int64_t rows;       // index into Lsi of the supernode's row list
     int32_t ld, diag, b;
-    int32_t row0, nrows;    // update kernels: rows [row0, row0 + nrows) of the panel (below the block)
+    int32_t row0, nrows;    // row tile: rows [row0, row0 + nrows) of the panel (below the block); nrows == 0: the diagonal task
     int32_t first_col;      // Super[s]
+    int32_t flag;           // index into the solve's sync words: forward = "x_blk is solved" flag, backward = tile counter
+    int32_t expect;         // backward diagonal task: number of row tiles to wait for
 };
-void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st, int unit = 0);
-void launch_solve_fwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
-void launch_solve_bwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
-void launch_solve_bwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st);
+// forward launch: tasks = the step's diagonal tasks, then its row tiles; backward launch: the row tiles, then the diagonal
+// tasks.  sync: one word per (panel, step) and direction, zero at the start of the solve; ticket: zero, private to the launch
+void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, int* sync, int* ticket,
+                      int* info, hipStream_t st);
+void launch_solve_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
+                      hipStream_t st);
 
 }  // namespace sf

@@ -275,90 +275,137 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Triangular solves with the resident Cholesky factor (L L^T x = b, permuted space), 64-column block steps.
-//   forward : x_blk <- D^{-1} x_blk (one wave, row r of D in lane r's registers) ; x[rows below] -= L[rows, blk] x_blk
-//   backward: x_blk -= L[rows below, blk]^T x[rows below]                        ; x_blk <- D^{-T} x_blk
-// Several supernodes of one level update the same ancestor entries of x: fp64 atomics.
+// Triangular solves with the resident factor (L L^T x = b or L U x = b, permuted space; reference: scalar host loops,
+// C:3074-3134, L:3592-3700), one launch per (level, 64-column step) and sweep direction:
+//   forward : x_blk <- D^{-1} x_blk (one wave, row r of D in lane r's registers)  ;  x[rows below] -= L[rows, blk] x_blk
+//   backward: x_blk -= L[rows below, blk]^T x[rows below]                         ;  x_blk <- D^{-T} x_blk
+// The two halves of a step run in ONE launch and hand over inside it, like k_step: tasks are claimed by ticket in
+// execution order (the producers come first in the list, so they are always running before a consumer can wait).
+//   forward : the 256-row tiles load their 64 columns into registers WHILE the diagonal wave solves, then wait for
+//             its flag, read x_blk and subtract their dot products (fp64 atomics: supernodes of one level share ancestors)
+//   backward: the tiles reduce their columns and add the partial sums to x_blk atomically, then count themselves in;
+//             the diagonal wave loads D meanwhile and solves once the count is complete
+// The substitution has no division on its 64-step chain: lane j forms 1 / D(j,j) up front.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-k_solve_fwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, double* __restrict__ x, int unit) {
-    const SolveTask t = tasks[blockIdx.x];
-    const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
-    const int lane = threadIdx.x, b = t.b;
-    const int64_t ld = t.ld;
-    double a[NB];       // unit: the diagonal is implied (LU: the L panel stores only the strictly lower part)
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        // unconditional load from a clamped address, then select: a load under a per-element condition becomes a branch
-        // plus its own s_waitcnt, i.e. 64 dependent round trips (26 of this kernel's 31 us)
-        const double v = D[min(lane, b - 1) + (int64_t)min(c, b - 1) * ld];
-        a[c] = (lane < b && c + unit <= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+constexpr int SV_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ void sv_publish(int* flag, int value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void sv_wait(const int* flag, int value, int* info) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > SV_SPIN_LIMIT) { atomicOr(info, 2); break; }
     }
-    double* xb = x + t.first_col + t.diag;
-    double v = (lane < b) ? xb[lane] : 0.0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double xj = readlane_f64(v, j) / readlane_f64(a[j], j);
-        if (lane == j) v = xj;
-        if (lane > j) v -= a[j] * xj;
-    }
-    if (lane < b) xb[lane] = v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ void __launch_bounds__(256)
-k_solve_fwd_update(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
-                   double* __restrict__ x) {
+k_solve_fwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
+            double* __restrict__ x, int unit, int* __restrict__ sync, int* __restrict__ ticket, int* __restrict__ info) {
+    __shared__ int s_ticket;
     __shared__ double xb[NB];
-    const SolveTask t = tasks[blockIdx.x];
-    const int tid = threadIdx.x;
-    if (tid < NB) xb[tid] = (tid < t.b) ? x[t.first_col + t.diag + tid] : 0.0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (tid >= t.nrows) return;
-    const int r = t.row0 + tid;
-    const double* Lr = Lsx + t.panel + r + (int64_t)t.diag * t.ld;
+    const SolveTask t = tasks[__builtin_amdgcn_readfirstlane(s_ticket)];
+    const int b = t.b;
+    const int64_t ld = t.ld;
+    if (t.nrows == 0) {                 // diagonal task: wave 0 solves, the others leave
+        if (tid >= 64) return;
+        const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * ld;
+        double a[NB];       // unit: the diagonal is implied (LU: the L panel stores only the strictly lower part)
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            // unconditional load from a clamped address, then select: a load under a per-element condition becomes a branch
+            // plus its own s_waitcnt, i.e. 64 dependent round trips
+            const double v = D[min(lane, b - 1) + (int64_t)min(c, b - 1) * ld];
+            a[c] = (lane < b && c + unit <= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+        }
+        double* xq = x + t.first_col + t.diag;
+        double v = (lane < b) ? xq[lane] : 0.0;
+        double dinv = 1.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) dinv = (c == lane) ? 1.0 / a[c] : dinv;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
+            if (lane == j) v = xj;
+            if (lane > j) v -= a[j] * xj;
+        }
+        if (lane < b) xq[lane] = v;
+        if (lane == 0) sv_publish(sync + t.flag, 1); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // row tile: this thread's row of the 64 columns, in flight while the diagonal block is solved
+    const int r = t.row0 + min(tid, t.nrows - 1);
+    const double* Lr = Lsx + t.panel + r + (int64_t)t.diag * ld;
+    double lr[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) lr[k] = Lr[(int64_t)min(k, b - 1) * ld];
+    const int32_t gi = Lsi[t.rows + r];
+    if (tid == 0) sv_wait(sync + t.flag, 1, info);
+    __syncthreads();
+    if (tid < NB) xb[tid] = (tid < b) ? __builtin_nontemporal_load(x + t.first_col + t.diag + tid) : 0.0;
+    __syncthreads();
     double acc = 0.0;
-    for (int k = 0; k < t.b; ++k) acc += Lr[(int64_t)k * t.ld] * xb[k];
-    unsafeAtomicAdd(x + Lsi[t.rows + r], -acc);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc += lr[k] * xb[k];       // columns beyond b meet xb = 0
+    if (tid < t.nrows) unsafeAtomicAdd(x + gi, -acc);
 }
 
-// one workgroup per tile of up to 256 rows; wave w sums columns 16 w .. 16 w + 15 of the block over the tile's rows,
-// four columns at a time (independent loads in flight), one atomic per column
+// row tiles: wave w sums columns 16 w .. 16 w + 15 of the block over the tile's rows, four columns at a time (independent
+// loads in flight), one atomic per column, then the tile counts itself in; diagonal task: waits for `expect` tiles
 __global__ void __launch_bounds__(256)
-k_solve_bwd_update(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
-                   double* __restrict__ x) {
+k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
+            double* __restrict__ x, int* __restrict__ sync, int* __restrict__ ticket, int* __restrict__ info) {
+    __shared__ int s_ticket;
     __shared__ double xr[256];
-    const SolveTask t = tasks[blockIdx.x];
+    __shared__ double Dl[NB][NB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    xr[tid] = (tid < t.nrows) ? x[Lsi[t.rows + t.row0 + tid]] : 0.0;
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const double* Lt = Lsx + t.panel + t.row0 + (int64_t)t.diag * t.ld;
-    for (int c0 = wave * 16; c0 < min(wave * 16 + 16, t.b); c0 += 4) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const SolveTask t = tasks[__builtin_amdgcn_readfirstlane(s_ticket)];
+    const int b = t.b;
+    if (t.nrows > 0) {
+        xr[tid] = (tid < t.nrows) ? x[Lsi[t.rows + t.row0 + tid]] : 0.0;
+        __syncthreads();
+        const double* Lt = Lsx + t.panel + t.row0 + (int64_t)t.diag * t.ld;
+        for (int c0 = wave * 16; c0 < min(wave * 16 + 16, b); c0 += 4) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double* col = Lt + (int64_t)min(c0 + u, t.b - 1) * t.ld;
+            for (int u = 0; u < 4; ++u) {
+                const double* col = Lt + (int64_t)min(c0 + u, b - 1) * t.ld;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = lane + 64 * q;
-                acc[u] += ((i < t.nrows) ? col[i] : 0.0) * xr[i];
+                for (int q = 0; q < 4; ++q) {
+                    const int i = lane + 64 * q;
+                    acc[u] += col[min(i, t.nrows - 1)] * xr[i];         // rows beyond the tile meet xr = 0
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double v = acc[u];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0 && c0 + u < b) unsafeAtomicAdd(x + t.first_col + t.diag + c0 + u, -v);
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            double v = acc[u];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && c0 + u < t.b) unsafeAtomicAdd(x + t.first_col + t.diag + c0 + u, -v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(sync + t.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        return;
     }
-}
-
-__global__ void __launch_bounds__(64)
-k_solve_bwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, double* __restrict__ x) {
-    __shared__ double Dl[NB][NB + 1];
-    const SolveTask t = tasks[blockIdx.x];
+    if (tid >= 64) return;
     const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
-    const int lane = threadIdx.x, b = t.b;
     {   // Dl[c][r] = D(r,c), coalesced along r; all 64 loads in flight (clamped addresses), then the LDS stores
         double col[NB];
 #pragma unroll
@@ -366,32 +413,41 @@ k_solve_bwd_diag(const SolveTask* __restrict__ tasks, const double* __restrict__
 #pragma unroll
         for (int c = 0; c < NB; ++c) Dl[c][lane] = (lane < b && c < b && lane >= c) ? col[c] : 0.0;
     }
-    __syncthreads();
-    double bcol[NB];    // bcol[c] = D(c, lane): column `lane` of D, rows c >= lane
+    double bcol[NB];    // bcol[c] = D(c, lane): column `lane` of D, rows c >= lane (one wave: no barrier needed, LDS ops are in order)
 #pragma unroll
     for (int c = 0; c < NB; ++c) bcol[c] = (lane < b && c < b && c >= lane) ? Dl[lane][c] : ((c == lane) ? 1.0 : 0.0);
-    double* xb = x + t.first_col + t.diag;
-    double v = (lane < b) ? xb[lane] : 0.0;
+    double dinv = 1.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) dinv = (c == lane) ? 1.0 / bcol[c] : dinv;
+    if (t.expect > 0) {
+        if (lane == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(sync + t.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t.expect) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > SV_SPIN_LIMIT) { atomicOr(info, 2); break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    double* xq = x + t.first_col + t.diag;
+    double v = (lane < b) ? __builtin_nontemporal_load(xq + min(lane, b - 1)) : 0.0;
 #pragma unroll
     for (int j = NB - 1; j >= 0; --j) {
-        const double xj = readlane_f64(v, j) / readlane_f64(bcol[j], j);
+        const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
         if (lane == j) v = xj;
         if (lane < j) v -= bcol[j] * xj;           // D(j, lane) * x_j
     }
-    if (lane < b) xb[lane] = v;
+    if (lane < b) xq[lane] = v;
 }
 
-void launch_solve_fwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st, int unit) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd_diag, dim3(nt), dim3(64), 0, st, t, Lsx, x, unit);
+void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, int* sync, int* ticket,
+                      int* info, hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, unit, sync, ticket, info);
 }
-void launch_solve_fwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd_update, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x);
-}
-void launch_solve_bwd_update(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_bwd_update, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x);
-}
-void launch_solve_bwd_diag(const SolveTask* t, int nt, const double* Lsx, double* x, hipStream_t st) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_bwd_diag, dim3(nt), dim3(64), 0, st, t, Lsx, x);
+void launch_solve_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
+                      hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_bwd, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -697,6 +753,9 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
+    // (Cholesky diagonal tasks come with J == diag, i.e. no update: the block was brought up to date right-looking by the
+    // earlier steps of this outer block -- each step's row tile that holds a future diagonal block pushes its own X X^T
+    // into it, see the end of the kernel -- so the diagonal workgroup, the step's critical path, starts its POTRF at once)
     if (nhp > 0) {
         double (*Xs)[ST_KC][ST_XLD] = reinterpret_cast<double (*)[ST_KC][ST_XLD]>(smem);
         const int nch = 2 * nhp;
@@ -1000,6 +1059,39 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             for (int r = 0; r < 4; ++r) {
                 const int cj = 16 * q + fk + 4 * r;
                 if (ci < nrows && cj < b) Ag[ci + (int64_t)cj * ld] = x[r];
+            }
+            if (!LU && t.next_b > 0) {
+                // (push, see below) park X_q in LDS where Dt rows 16 q .. 16 q + 15 were: [k][row] image, dead once every
+                // wave has passed this iteration.  next_b > 0 implies b == 64: all waves run all four iterations.
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Dt[16 * q + fk + 4 * r][ci] = x[r];
+            }
+        }
+        if (!LU && t.next_b > 0) {
+            // These 64 rows are a FUTURE diagonal block of this outer block (rows = columns [row0, row0 + next_b) of the
+            // panel): subtract this step's contribution X X^T from it now (right-looking, lower triangle), so that its own
+            // step finds it up to date and its diagonal workgroup -- the step's critical path -- starts the POTRF at once.
+            // One workgroup per (step, future block), steps are separate launches: plain read-modify-write.
+            __syncthreads();
+            double* __restrict__ Dn = Lsx + t.panel + t.row0 + (int64_t)t.row0 * ld;
+            const int nb = t.next_b;
+            for (int ct = 0; ct <= wave; ++ct) {
+                double4_t d = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                for (int sg = 0; sg < 16; ++sg)         // A[i = cj][k], B[k][j = ci]
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(Dt[4 * sg + fk][16 * ct + fr], Dt[4 * sg + fk][ci], d, 0, 0, 0);
+                double old[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cj = 16 * ct + fk + 4 * r;
+                    old[r] = Dn[min(ci, nb - 1) + (int64_t)min(cj, nb - 1) * ld];               // unconditional, clamped
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cj = 16 * ct + fk + 4 * r;
+                    if (ci < nb && cj <= ci) Dn[ci + (int64_t)cj * ld] = old[r] - d[r];
+                }
             }
         }
     }

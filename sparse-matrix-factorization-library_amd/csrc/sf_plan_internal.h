@@ -127,7 +127,9 @@ struct sf_chol_plan {
     // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
     sf::SolveTask* d_solve = nullptr;
     double* d_x = nullptr;
-    struct SolveStep { int64_t diag_first; int diag_count; int64_t fwd_first; int fwd_count; int64_t bwd_first; int bwd_count; };
+    struct SolveStep { int64_t fwd_first, bwd_first; int count; };   // both launches of a step have `count` tasks
+    int* d_solve_sync = nullptr;
+    int n_solve_sync = 0;
     std::vector<SolveStep> solve_steps;
     double last_solve_ms = 0;
     int device = 0;
