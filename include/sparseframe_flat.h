@@ -214,6 +214,19 @@ int sf_lu_plan_create_distributed(sf_lu_plan **plan, int device, sf_long n, sf_l
                                   const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
                                   const int32_t *phase, int load_top, int rank, int nranks);
 int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *Ux /* NULL if U aliases L */);
+/* Pivoting (BASELINE config 5 asks for it, the reference has none: magma_dgetrf_nopiv L:2653, devIpiv = NULL
+ * L:3344, static pre-pivot L:589-673 disabled).  The symbolic structure is static, so rows can only be exchanged where that
+ * keeps the structure: INSIDE the 64 x 64 diagonal block of a 64-column step.  Threshold partial pivoting there -- the natural
+ * row keeps the pivot while |a_jj| >= tol * max over the block's unused rows of |a_ij| -- and a pivot smaller than
+ * perturb * max|a_ij| is replaced by +- that value ("perturbed_pivots" stat; refine the solution iteratively then).
+ * tol in [0, 1]: 0 = no pivoting (exactly the reference's behaviour; a zero pivot is SF_ERR_NOT_POSDEF when perturb is 0 too),
+ * 1 = partial pivoting.  Defaults: tol 0.1, perturb sqrt(eps) (env SF_LU_PIVOT_TOL / SF_LU_PERTURB at plan creation).  On a
+ * matrix whose natural pivots pass the threshold (e.g. diagonally dominant) the factor is bit-identical to the no-pivot one.
+ * The interchanges are recorded per block and applied block by block in the forward solve (LINPACK-style: the L entries to
+ * the left of a block keep their rows). */
+int sf_lu_plan_set_pivoting(sf_lu_plan *plan, double tol, double perturb);
+/* pivpos[g] = row position (global permuted index, inside the same 64-column block) of original row g; n entries */
+int sf_lu_plan_get_pivots(sf_lu_plan *plan, sf_long *pivpos);
 int sf_lu_plan_factorize(sf_lu_plan *plan, int sync);
 int sf_lu_plan_sync(sf_lu_plan *plan);
 /* D2H copy of the factor gathered into the reference layout: panel s = (2*nsrow-nscol) x nscol column-major,
@@ -235,7 +248,8 @@ int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_inf
                           sf_long n, sf_long nsuper, const sf_long *Super, const sf_long *SuperMap,
                           const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                           const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
-                          const sf_float *Lx, const sf_float *Ux, sf_float *Lsx_out);
+                          const sf_float *Lx, const sf_float *Ux, sf_float *Lsx_out,
+                          sf_long *PivOut /* LU: row positions after the in-block interchanges (n entries), or NULL */);
 
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
 int sf_device_count(void);

@@ -135,6 +135,10 @@ lib.sf_lu_plan_create_distributed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.
 lib.sf_lu_plan_create_distributed.restype = C.c_int
 lib.sf_lu_plan_set_values.argtypes = [C.c_void_p, c_double_p, c_double_p]
 lib.sf_lu_plan_set_values.restype = C.c_int
+lib.sf_lu_plan_set_pivoting.argtypes = [C.c_void_p, C.c_double, C.c_double]
+lib.sf_lu_plan_set_pivoting.restype = C.c_int
+lib.sf_lu_plan_get_pivots.argtypes = [C.c_void_p, c_long_p]
+lib.sf_lu_plan_get_pivots.restype = C.c_int
 lib.sf_lu_plan_factorize.argtypes = [C.c_void_p, C.c_int]
 lib.sf_lu_plan_factorize.restype = C.c_int
 lib.sf_lu_plan_sync.argtypes = [C.c_void_p]

@@ -357,6 +357,17 @@ class LUPlan(_ShardedPlanMixin):
             Ux = _f64(Ux)
             check(lib.sf_lu_plan_set_values(self._h, _dp(Lx), _dp(Ux)), "sf_lu_plan_set_values")
 
+    def set_pivoting(self, tol=0.1, perturb=1.4901161193847656e-08):
+        """threshold partial pivoting inside the 64 x 64 diagonal blocks (tol in [0, 1]; 0 = none, the reference's behaviour)
+        and the perturbation of tiny pivots (relative to max|a_ij|; 0 = a zero pivot is an error)"""
+        check(lib.sf_lu_plan_set_pivoting(self._h, float(tol), float(perturb)), "sf_lu_plan_set_pivoting")
+
+    def get_pivots(self):
+        """pivpos[g] = row position of original row g after the in-block interchanges (identity where nothing moved)"""
+        out = np.arange(max(self.n, 1), dtype=np.int64)
+        check(lib.sf_lu_plan_get_pivots(self._h, _lp(out)), "sf_lu_plan_get_pivots")
+        return out[:self.n]
+
     def factorize(self, sync=True):
         check(lib.sf_lu_plan_factorize(self._h, 1 if sync else 0), "sf_lu_plan_factorize")
 

@@ -22,6 +22,7 @@
 #include <sparseframe_hip.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,7 +62,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -339,7 +340,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         const int b = std::min(sf::NB, nscol - diag);
                         flag_of.push_back(n_flags);
                         // Cholesky: J = diag (no left-looking update): the diagonal block arrives up to date, see k_step
-                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, lu ? J : diag, diag, b, diag, b, n_flags++, 0, (int32_t)(steps.size() - d0), 0});
+                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, lu ? J : diag, diag, b, diag, b, n_flags++, 0, (int32_t)(steps.size() - d0), 0, (int32_t)Super[s], 0});
                         slot_of.push_back((int32_t)(steps.size() - 1 - d0));
                         if (ti > 0) p->flops_panel_gemm += (lu ? 2.0 : 1.0) * ((double)b * (b + 1) * (diag - J) + 2.0 * (nsrow - diag - b) * (double)b * (diag - J));
                     }
@@ -355,10 +356,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                             if (!lu) {
                                 // rows that are a later diagonal block of this outer block get this step's X X^T pushed into them
                                 const int nb = (r < std::min(nscol, J + sf::OUTER_NB)) ? std::min(sf::NB, nscol - r) : 0;
-                                steps.push_back(StepTask{XP[s], XP[s], nsrow, J, diag, b, r, nr, fl, 0, sl, nb});
+                                steps.push_back(StepTask{XP[s], XP[s], nsrow, J, diag, b, r, nr, fl, 0, sl, nb, (int32_t)Super[s], 0});
                             } else {
-                                steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, diag, b, r, nr, fl, 0, sl, 0});     // L21 <- (L21 - ..) U11^{-1}
-                                steps.push_back(StepTask{XP[s] + ushift, XP[s], nsrow, J, diag, b, r, nr, fl, 1, sl, 0});     // U12^T <- (U12^T - ..) L11^{-T}
+                                steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, diag, b, r, nr, fl, 0, sl, 0, (int32_t)Super[s], 0});     // L21 <- (L21 - ..) U11^{-1}
+                                steps.push_back(StepTask{XP[s] + ushift, XP[s], nsrow, J, diag, b, r, nr, fl, 1, sl, 0, (int32_t)Super[s], 0});     // U12^T <- (U12^T - ..) L11^{-T}
                             }
                         }
                     }
@@ -390,15 +391,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                             add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K);
                         }
                     }
-                    potrf.push_back(PotrfTask{XP[s], nsrow, diag, b, 0});
+                    potrf.push_back(PotrfTask{XP[s], nsrow, diag, b, (int32_t)Super[s]});
                     const int below = diag + b;
                     for (int r = below; r < nsrow; r += sf::TRSM_ROWS) {
                         const int nr = std::min(sf::TRSM_ROWS, nsrow - r);
                         if (!lu) {
-                            trsm.push_back(TrsmTask{XP[s], XP[s], nsrow, diag, b, r, nr, 0});
+                            trsm.push_back(TrsmTask{XP[s], XP[s], nsrow, diag, b, r, nr, 0, (int32_t)Super[s], 0});
                         } else {
-                            trsm.push_back(TrsmTask{XP[s], XP[s] + ushift, nsrow, diag, b, r, nr, 0});            // L21 <- L21 U11^{-1}
-                            trsm.push_back(TrsmTask{XP[s] + ushift, XP[s], nsrow, diag, b, r, nr, 1});            // U12^T <- U12^T L11^{-T}
+                            trsm.push_back(TrsmTask{XP[s], XP[s] + ushift, nsrow, diag, b, r, nr, 0, (int32_t)Super[s], 0});            // L21 <- L21 U11^{-1}
+                            trsm.push_back(TrsmTask{XP[s] + ushift, XP[s], nsrow, diag, b, r, nr, 1, (int32_t)Super[s], 0});            // U12^T <- U12^T L11^{-T}
                         }
                     }
                 }
@@ -671,6 +672,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             if ((rc = upload(&p->d_loadmask, mask, &p->bytes_device))) break;
         }
         if (lu) {
+            // pivot records: pivpos | pivinv, n entries each, + the perturbation counter; identity until a factorization with
+            // pivoting overwrites the blocks it interchanges
+            const size_t pb = (size_t)(2 * std::max<int64_t>(n, 1) + 1) * sizeof(int32_t);
+            if (hipMalloc((void**)&p->d_piv, pb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += pb;
+            if (const char* env = getenv("SF_LU_PIVOT_TOL")) p->piv_tol = atof(env);
+            if (const char* env = getenv("SF_LU_PERTURB")) p->piv_perturb = atof(env);
             if (!p->u_alias) {
                 if ((rc = upload(&p->d_Up, Up64, &p->bytes_device))) break;
                 if ((rc = upload(&p->d_Ui, Ui32, &p->bytes_device))) break;
@@ -742,6 +750,12 @@ int sf_lu_plan_set_values(sf_lu_plan* p, const sf_float* Lx, const sf_float* Ux)
     HIP_TRY(hipSetDevice(p->device));
     if (p->nnz > 0) HIP_TRY(hipMemcpyAsync(p->d_Lx, Lx, p->nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
     if (!p->u_alias && p->unz > 0) HIP_TRY(hipMemcpyAsync(p->d_Ux, Ux, p->unz * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    {   // max |a_ij|: scale of the pivot perturbation
+        double m = 0;
+        for (int64_t k = 0; k < p->nnz; ++k) m = std::max(m, std::fabs(Lx[k]));
+        if (!p->u_alias) for (int64_t k = 0; k < p->unz; ++k) m = std::max(m, std::fabs(Ux[k]));
+        p->amax = m;
+    }
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->values_set = true;
     return SF_OK;
@@ -755,6 +769,7 @@ int sf_chol_plan_sync(sf_chol_plan* p) {
     HIP_TRY(hipMemcpy(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
     float ms = 0;
     if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_ms = ms;
+    if (p->lu) HIP_TRY(hipMemcpy(&p->last_perturbed, p->d_piv + 2 * std::max<int64_t>(p->n, 1), sizeof(int), hipMemcpyDeviceToHost));
     // 1: non-positive / zero pivot; 2: a fused step's flag wait timed out (internal error, never seen)
     p->last_status = (info & 2) ? SF_ERR_HIP : (info ? SF_ERR_NOT_POSDEF : SF_OK);
     return p->last_status;
@@ -800,6 +815,16 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         p->packed_pending = -1;
         p->epoch = (p->epoch == 0x7fffffff) ? 1 : p->epoch + 1;     // flag value of this factorization's fused steps (never 0)
     }
+    sf::PivotCtl pc{0.0, 0.0, nullptr, nullptr, nullptr};
+    if (p->lu) {
+        const bool piv = p->piv_tol > 0.0;
+        pc.tol = p->piv_tol;
+        pc.eps = p->piv_perturb * p->amax;
+        pc.pivpos = piv ? p->d_piv : nullptr;
+        pc.pivinv = piv ? p->d_piv + std::max<int64_t>(p->n, 1) : nullptr;
+        pc.nperturb = (int*)(p->d_piv + 2 * std::max<int64_t>(p->n, 1));
+        if (first) HIP_TRY(hipMemsetAsync(pc.nperturb, 0, sizeof(int), st));
+    }
     if (first) {
         HIP_TRY(hipMemsetAsync(p->d_info, 0, (1 + p->n_tickets) * sizeof(int), st));
         if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
@@ -826,10 +851,10 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         const Launch& L = p->launches[li];
         switch (L.kind) {
             case 0:
-                if (p->lu) sf::launch_getrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->xC, p->d_info, st);
+                if (p->lu) sf::launch_getrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->xC, p->d_info, pc, st);
                 else sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st);
                 break;
-            case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, st); break;
+            case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, pc.pivinv, st); break;
             case 6: {       // k_update_small; a split launch (distributed top): this rank's share of the tiles (the update is a sum)
                 int64_t lo = 0, hi = L.count;
                 if (L.split) { lo = (int64_t)L.count * p->rank / p->nranks; hi = (int64_t)L.count * (p->rank + 1) / p->nranks; }
@@ -838,7 +863,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             }
             case 5:
                 sf::launch_step(p->d_steps + L.first, L.count, p->lu ? 1 : 0, p->d_Lsx, p->d_flags, p->epoch, p->d_info, p->d_tinv,
-                                p->d_info + 1 + L.ticket, st);
+                                p->d_info + 1 + L.ticket, pc, st);
                 break;
             case 2:
             case 3:
@@ -1170,6 +1195,33 @@ int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
     return SF_OK;
 }
 
+int sf_lu_plan_set_pivoting(sf_lu_plan* p, double tol, double perturb) {
+    if (!p || !p->lu || !(tol >= 0.0) || tol > 1.0 || !(perturb >= 0.0)) return SF_ERR_ARG;
+    p->piv_tol = tol;
+    p->piv_perturb = perturb;
+    return SF_OK;
+}
+
+// pivpos[g] (global permuted index) = the row position original row g was given by the interchanges of its 64-column
+// block; the identity where nothing moved, for panels not stored on this rank (left untouched) and when pivoting is off
+int sf_lu_plan_get_pivots(sf_lu_plan* p, sf_long* pivpos) {
+    if (!p || !p->lu || (!pivpos && p->n > 0)) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!(p->piv_tol > 0.0)) {
+        for (int64_t s = 0; s < p->nsuper; ++s)
+            if (p->h_XP[s] >= 0)
+                for (int64_t j = p->h_Super[s]; j < p->h_Super[s + 1]; ++j) pivpos[j] = j;
+        return SF_OK;
+    }
+    std::vector<int32_t> h(std::max<int64_t>(p->n, 1));
+    HIP_TRY(hipMemcpy(h.data(), p->d_piv, p->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t s = 0; s < p->nsuper; ++s)
+        if (p->h_XP[s] >= 0)
+            for (int64_t j = p->h_Super[s]; j < p->h_Super[s + 1]; ++j) pivpos[j] = h[j];
+    return SF_OK;
+}
+
 int sf_lu_plan_factorize(sf_lu_plan* p, int sync) { return (p && p->lu) ? sf_chol_plan_factorize(p, sync) : SF_ERR_ARG; }
 int sf_lu_plan_sync(sf_lu_plan* p) { return sf_chol_plan_sync(p); }
 int sf_lu_plan_get_factor(sf_lu_plan* p, sf_float* Lsx) { return (p && p->lu) ? sf_chol_plan_get_factor(p, Lsx) : SF_ERR_ARG; }
@@ -1191,6 +1243,8 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     const std::string k(name);
     if (k == "levels") return p->nlevels;
     if (k == "last_solve_ms") return p->last_solve_ms;
+    if (k == "perturbed_pivots") return (double)p->last_perturbed;
+    if (k == "pivot_tol") return p->piv_tol;
     if (k == "last_to_host_ms") return p->last_to_host_ms;
     if (k == "download_pieces") return (double)p->dl_pieces.size();
     if (k == "top_doubles") return (double)p->top_size;
@@ -1239,7 +1293,8 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + 2 * nst) * sizeof(int), st));
     for (size_t k = 0; k < nst; ++k) {
         const auto& s = p->solve_steps[k];
-        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.count, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0, sync, tickets + 2 * k,
+        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.count, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
+                             (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, sync, tickets + 2 * k,
                              p->d_solve_sync, st);
     }
     for (size_t k = nst; k-- > 0;) {

@@ -114,7 +114,7 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
                                   sf_long n, sf_long nsuper, const sf_long* Super, const sf_long* SuperMap,
                                   const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                                   const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
-                                  const sf_float* Lx, const sf_float* Ux, sf_float* Lsx_out) {
+                                  const sf_float* Lx, const sf_float* Ux, sf_float* Lsx_out, sf_long* PivOut) {
     const int N = common->numGPU;
     MultiState& M = *list[0].st->multi;
     PlanKey key = make_key(lu, n, nsuper, Super, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui);
@@ -177,6 +177,9 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
     for (std::thread& t : th) t.join();
     for (int r = 0; r < N; ++r)
         if (rcs[r]) return rcs[r];
+    if (lu && PivOut)      // every rank reports the blocks of the panels it stores (the top panels' records agree on all ranks)
+        for (int r = 0; r < N; ++r)
+            if (int rc = sf_lu_plan_get_pivots(entry->plans[r], PivOut)) return rc;
     return SF_OK;
 }
 
@@ -243,7 +246,7 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
                           sf_long n, sf_long nsuper, const sf_long* Super, const sf_long* SuperMap,
                           const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                           const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
-                          const sf_float* Lx, const sf_float* Ux, sf_float* Lsx_out) {
+                          const sf_float* Lx, const sf_float* Ux, sf_float* Lsx_out, sf_long* PivOut) {
     if (!common || !Lsx_out || !Super || !Lsip || !Lsxp || !Lp || n < 0 || nsuper < 0) return SF_ERR_ARG;
     if (common->numGPU <= 0 || !list) {
         fprintf(stderr, "[sparseframe-hip] SparseFrame_factorize: no GPU handler (numGPU = %d); no CPU fallback\n", common->numGPU);
@@ -255,7 +258,7 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
     if (common->numGPU > 1 && nsuper > 0 && list[0].st && list[0].st->multi) {
         const char* mode = getenv("SF_MULTI");
         if (!mode || strcmp(mode, "matrix") != 0)
-            return factorize_all_handlers(common, list, lu, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, Lx, Ux, Lsx_out);
+            return factorize_all_handlers(common, list, lu, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, Lx, Ux, Lsx_out, PivOut);
     }
     // one matrix = one handler; the caller's matrix threads (MATRIX_THREAD_NUM, C:3375) are spread over the devices
     struct gpu_info_struct& H = list[(serial >= 0 ? serial : 0) % common->numGPU];
@@ -293,7 +296,8 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
         S.cache.push_back(HandlerState::Entry{key, plan, ++S.clock});
     }
     const auto tk2 = std::chrono::steady_clock::now();
-    const int rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
+    int rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
+    if (!rc && lu && PivOut) rc = sf_lu_plan_get_pivots(plan, PivOut);
     if (trace) {
         const auto tk3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -310,7 +314,7 @@ int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct g
                                      struct matrix_info_struct* mi) {
     if (!common || !mi || !mi->Lsx) return SF_ERR_ARG;
     return sf_handlers_factorize(common, list, 0, mi->serial, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi,
-                                 mi->Lsxp, mi->Lp, mi->Li, nullptr, nullptr, mi->Lx, nullptr, mi->Lsx);
+                                 mi->Lsxp, mi->Lp, mi->Li, nullptr, nullptr, mi->Lx, nullptr, mi->Lsx, nullptr);
 }
 
 int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {

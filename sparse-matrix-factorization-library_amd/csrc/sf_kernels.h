@@ -51,7 +51,24 @@ struct GemmTask {   // one 128x128 tile of a problem over ONE slice of its K ran
 struct PotrfTask {  // factor the b x b diagonal block at (diag, diag) of a panel
     int64_t panel;      // doubles, into Lsx
     int32_t ld, diag, b;
-    int32_t pad;
+    int32_t first_col;  // Super[s]: the block's rows are the global (permuted) indices first_col + diag + [0, b)  (LU pivot records)
+};
+
+// LU pivoting (the reference never pivots, L:2653 / L:3344, and keeps a disabled static pre-pivot,
+// L:589-673): threshold partial pivoting RESTRICTED to the 64 x 64 diagonal block of a step -- the symbolic structure is
+// static, rows outside the block cannot be exchanged -- with a perturbation fallback.
+//   tol  > 0 : at column j the natural row keeps the pivot while |a_jj| >= tol * max_i |a_ij| (i over the block's rows not
+//              yet used); otherwise the row of the largest entry takes it.  tol = 0: no pivoting (the reference's behaviour).
+//   eps  > 0 : a pivot smaller than eps in magnitude is replaced by +-eps (counted in *nperturb); eps = 0: a zero pivot is an
+//              error (info bit 0) as before.
+//   pivpos[g] = position (global index, inside the same block) that original row g of the block ends up in; pivinv = inverse.
+// Only the block's rows of the block's own columns and of the columns to its RIGHT move (the U rows); the L entries to the
+// left of the block stay where they are, so the interchanges are applied LINPACK-style, block by block, in the forward solve.
+struct PivotCtl {
+    double tol, eps;
+    int32_t* pivpos;    // n entries each, or nullptr when tol == 0 (then no record is written: positions are the identity)
+    int32_t* pivinv;
+    int* nperturb;
 };
 
 struct TrsmTask {   // rows [row0, row0+nrows) of panel columns [diag, diag+b) <- X * D^{-T}
@@ -59,7 +76,10 @@ struct TrsmTask {   // rows [row0, row0+nrows) of panel columns [diag, diag+b) <
     int64_t dpanel;     // panel holding the triangular block D at (diag, diag) (same ld); Cholesky: == panel
     int32_t ld, diag, b;
     int32_t row0, nrows;
-    int32_t unit;       // 1: D has an implicit unit diagonal (LU: U12^T <- U12^T * L11^{-T})
+    int32_t unit;       // 1: D has an implicit unit diagonal (LU: U12^T <- U12^T * L11^{-T}); with pivoting the tile's columns are
+                        // first brought into pivot order (they are rows of U)
+    int32_t first_col;  // Super[s]
+    int32_t pad;
 };
 
 struct StepTask {   // fused 64-column step on rows [row0, row0+nrows) of panel columns [diag, diag+b), updated by columns [J, diag)
@@ -74,6 +94,8 @@ struct StepTask {   // fused 64-column step on rows [row0, row0+nrows) of panel 
     int32_t slot;           // index (within the launch) of the diagonal task whose 16 x 16 inverses the rows use
     int32_t next_b;         // row task, Cholesky: > 0 = these rows are a future diagonal block of the outer block, next_b wide:
                             // push X X^T into it
+    int32_t first_col;      // Super[s] (LU pivot records)
+    int32_t pad;
 };
 
 // skip_diag != 0: entries with row == column are not stored (LU: the L panel)
@@ -83,19 +105,20 @@ void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, 
 void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st);
 // LU: the diagonal block is split over two panels, L (strictly lower, at Lsx + task.panel) and U^T (lower
 // including the diagonal, at Lsx + task.panel + u_shift)
-void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, hipStream_t st);
+void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, PivotCtl pc, hipStream_t st);
 // LU: gather the (L, U^T) panel pairs into the reference's (2*nsrow - nscol) x nscol panels (LU/Source/SparseFrame.c:2514-2517):
 // values [e_begin, e_end) of that layout -> out[0 .. e_end - e_begin)
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
                     const double* PL, const double* PU, double* out, int64_t e_begin, int64_t e_end, hipStream_t st);
-void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st);
+// pivinv != nullptr (LU with pivoting): the unit tasks (U^T rows) permute their columns by the block's interchanges first
+void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, const int32_t* pivinv, hipStream_t st);
 // tasks: the diagonal blocks first, then the 64-row tiles below them, any number (the grid need not be co-resident:
 // workgroups claim tasks in execution order through *ticket, which must be 0 at launch and is private to the launch);
 // flags[task.flag] == epoch once that diagonal block is factored
 // lu != 0: the diagonal tasks hold (L panel, U^T panel) and are factored without pivoting
 // tinv: scratch for the 16 x 16 inverses, 1024 (Cholesky) / 2048 (LU: of U11^T, then of L11) doubles per diagonal task of the launch
 void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, int* ticket,
-                 hipStream_t st);
+                 PivotCtl pc, hipStream_t st);
 // One-time (plan creation): relative maps of all scatter problems [first, first+count) -- the device form of the
 // reference's createRelativeMap (cuda_kernel.cu:42-60): RelMap[map_off + ci] = position of source row ci in the
 // target supernode's row list.
@@ -123,8 +146,9 @@ struct SolveTask {
 };
 // forward launch: tasks = the step's diagonal tasks, then its row tiles; backward launch: the row tiles, then the diagonal
 // tasks.  sync: one word per (panel, step) and direction, zero at the start of the solve; ticket: zero, private to the launch
-void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, int* sync, int* ticket,
-                      int* info, hipStream_t st);
+// pivpos != nullptr (LU with pivoting): x_blk is brought into the block's pivot order before the unit-lower solve
+void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
+                      int* sync, int* ticket, int* info, hipStream_t st);
 void launch_solve_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
                       hipStream_t st);
 

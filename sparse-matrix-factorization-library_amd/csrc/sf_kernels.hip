@@ -23,6 +23,7 @@
 //
 // Wavefronts are 64 wide; all tilings below are written for that.
 #include "sf_kernels.h"
+#include "sf_wave.h"
 
 namespace sf {
 
@@ -131,14 +132,62 @@ void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// No-pivot LU of a b x b (b <= 64) diagonal block (reference: magma_dgetrf_nopiv, LU/Source/SparseFrame.c:2653,
-// cusolverDnDgetrf with devIpiv = NULL, :3344).  Same one-wavefront scheme as k_potrf_block: lane r holds row r
-// of the block, a[c] = D(r,c); at step j lane j's row is broadcast with v_readlane.  The block lives in two
-// panels: D(r,c), c < r (L, unit diagonal implied) in the L panel at (diag+r, diag+c); D(r,c), c >= r (U) in
-// the U^T panel at (diag+c, diag+r).
+// LU of a b x b (b <= 64) diagonal block in ONE wavefront, lane r holds row r (a[c] = D(r,c), identity padding), the same
+// register scheme as k_potrf_block.  Without pivoting this is the reference's magma_dgetrf_nopiv (LU/Source/SparseFrame.c:2653)
+// / cusolverDnDgetrf with devIpiv = NULL (:3344).  With pivoting (PivotCtl, sf_kernels.h) the interchanges are IMPLICIT: rows
+// never move between lanes; at column j a pivot lane p is chosen among the lanes not used yet, its row is broadcast with
+// v_readlane (p is wave-uniform), and the lane remembers the position it was given.  The permutation is applied when the
+// rows are stored.  RCP: multipliers by v_rcp_f64 + two Newton steps (k_step's variant) instead of the IEEE division.
+// Returns this lane's final position; bad: a zero / NaN pivot was met and not perturbed.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_dyn_f64(double v, int l) {      // l wave-uniform, not a compile-time constant
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <bool RCP>
+__device__ __forceinline__ int getrf_wave(double (&a)[NB], int lane, int b, double tol, double eps, bool& bad, int& nperturbed) {
+    int pos = lane;
+    bool active = lane < b;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int p = j;
+        if (tol > 0.0 && j < b) {               // wave-uniform: no pivot search when pivoting is off or in the padding
+            double m;
+            const int pm = wave_argmax_abs(a[j], active, &m);
+            const double nat = readlane_f64(a[j], j);
+            const bool nat_free = ((__ballot(active) >> j) & 1ull) != 0;
+            if (!(nat_free && fabs(nat) >= tol * m && nat != 0.0) && pm >= 0) p = pm;
+            p = __builtin_amdgcn_readfirstlane(p);
+        }
+        double piv = readlane_dyn_f64(a[j], p);
+        if (j < b && eps > 0.0 && !(fabs(piv) >= eps) && piv == piv) {      // tiny (or zero) pivot: perturb
+            piv = (piv < 0.0) ? -eps : eps;
+            ++nperturbed;
+            if (lane == p) a[j] = piv;
+        }
+        bad = bad || !(piv != 0.0);             // zero or NaN pivot; padded rows have piv = 1
+        const bool elim = active && lane != p;
+        double l;
+        if (RCP) {
+            double rp = __builtin_amdgcn_rcp(piv);
+            rp = rp * (2.0 - piv * rp);
+            rp = rp * (2.0 - piv * rp);
+            l = elim ? a[j] * rp : 0.0;
+        } else {
+            l = elim ? a[j] / piv : 0.0;
+        }
+        if (elim) a[j] = l;
+        if (lane == p) { pos = j; active = false; }
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_dyn_f64(a[c], p);
+    }
+    return pos;
+}
+
+// The block lives in two panels: D(r,c), c < r (L, unit diagonal implied) in the L panel at (diag+r, diag+c); D(r,c), c >= r
+// (U) in the U^T panel at (diag+c, diag+r).
 __global__ void __launch_bounds__(64)
-k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int64_t u_shift, int* __restrict__ info) {
+k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int64_t u_shift, int* __restrict__ info, PivotCtl pc) {
     const PotrfTask t = tasks[blockIdx.x];
     double* PLd = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
     double* PUd = PLd + u_shift;
@@ -154,27 +203,26 @@ k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int
         a[c] = v;
     }
     bool bad = false;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double piv = readlane_f64(a[j], j);
-        bad = bad || !(piv != 0.0);         // zero or NaN pivot; padded rows have piv = 1
-        const double l = (lane > j) ? a[j] / piv : 0.0;
-        if (lane > j) a[j] = l;
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_f64(a[c], j);
-    }
+    int np = 0;
+    const int pos = getrf_wave<false>(a, lane, b, pc.tol, pc.eps, bad, np);
     if (bad && lane == 0) atomicOr(info, 1);
+    if (np > 0 && lane == 0) atomicAdd(pc.nperturb, np);
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
         if (lane < b && c < b) {
-            if (c < lane) PLd[lane + c * ld] = a[c]; else PUd[c + lane * ld] = a[c];
+            if (c < pos) PLd[pos + c * ld] = a[c]; else PUd[c + pos * ld] = a[c];
         }
+    }
+    if (pc.pivpos && lane < b) {
+        const int g0 = t.first_col + t.diag;
+        pc.pivpos[g0 + lane] = g0 + pos;
+        pc.pivinv[g0 + pos] = g0 + lane;
     }
 }
 
-void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, hipStream_t st) {
+void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, PivotCtl pc, hipStream_t st) {
     if (ntasks <= 0) return;
-    hipLaunchKernelGGL(k_getrf_block, dim3(ntasks), dim3(64), 0, st, tasks, Lsx, u_shift, info);
+    hipLaunchKernelGGL(k_getrf_block, dim3(ntasks), dim3(64), 0, st, tasks, Lsx, u_shift, info, pc);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -223,7 +271,7 @@ void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp
 // and D is broadcast from LDS, transposed so that the 8 multipliers of one k are 64 contiguous bytes.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TRSM_ROWS)
-k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx) {
+k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx, const int32_t* __restrict__ pivinv) {
     __shared__ __attribute__((aligned(16))) double Dt[NB][NB];   // Dt[k][j] = L(j,k) for k < j, else 0
     __shared__ double Dinv[NB];
     const TrsmTask t = tasks[blockIdx.x];
@@ -241,6 +289,18 @@ k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx) {
     if (tid >= t.nrows) return;
     double* X = Lsx + t.panel + t.row0 + tid + (int64_t)t.diag * t.ld;
     const int64_t ld = t.ld;
+    if (pivinv && t.unit) {
+        // LU with pivoting: these are rows of U^T, i.e. the tile's columns are the block's rows of U -- bring them into
+        // pivot order first (column at position p <- original column pivinv[p]); all loads precede the stores
+        const int g0 = t.first_col + t.diag;
+        const int32_t* pv = pivinv + g0;
+        double tmp[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) tmp[c] = X[(int64_t)(pv[min(c, b - 1)] - g0) * ld];
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (c < b) X[(int64_t)c * ld] = tmp[c];
+    }
 
     for (int jb = 0; jb < b; jb += 8) {
         double acc[8];
@@ -269,9 +329,9 @@ k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx) {
     }
 }
 
-void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, hipStream_t st) {
+void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, const int32_t* pivinv, hipStream_t st) {
     if (ntasks <= 0) return;
-    hipLaunchKernelGGL(k_trsm_block, dim3(ntasks), dim3(TRSM_ROWS), 0, st, tasks, Lsx);
+    hipLaunchKernelGGL(k_trsm_block, dim3(ntasks), dim3(TRSM_ROWS), 0, st, tasks, Lsx, pivinv);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -308,7 +368,8 @@ __device__ __forceinline__ void sv_wait(const int* flag, int value, int* info) {
 
 __global__ void __launch_bounds__(256)
 k_solve_fwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
-            double* __restrict__ x, int unit, int* __restrict__ sync, int* __restrict__ ticket, int* __restrict__ info) {
+            double* __restrict__ x, int unit, const int32_t* __restrict__ pivpos, int* __restrict__ sync, int* __restrict__ ticket,
+            int* __restrict__ info) {
     __shared__ int s_ticket;
     __shared__ double xb[NB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -330,6 +391,13 @@ k_solve_fwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
         }
         double* xq = x + t.first_col + t.diag;
         double v = (lane < b) ? xq[lane] : 0.0;
+        if (pivpos) {
+            // LU with pivoting: the block's row interchanges, applied here (LINPACK-style: the L entries to the left of a
+            // block were stored at their rows' original places, so x is permuted block by block as the sweep reaches it)
+            const int g0 = t.first_col + t.diag;
+            if (lane < b) xb[pivpos[g0 + lane] - g0] = v;
+            v = (lane < b) ? xb[lane] : 0.0;     // one wave: LDS operations complete in order
+        }
         double dinv = 1.0;
 #pragma unroll
         for (int c = 0; c < NB; ++c) dinv = (c == lane) ? 1.0 / a[c] : dinv;
@@ -441,9 +509,9 @@ k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
     if (lane < b) xq[lane] = v;
 }
 
-void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, int* sync, int* ticket,
-                      int* info, hipStream_t st) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, unit, sync, ticket, info);
+void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
+                      int* sync, int* ticket, int* info, hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, unit, pivpos, sync, ticket, info);
 }
 void launch_solve_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
                       hipStream_t st) {
@@ -714,7 +782,7 @@ constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 template <bool LU>
 __global__ void __launch_bounds__(256, LU ? 2 : 3)   // LU: the unblocked GETRF keeps a 64-value row per lane
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info,
-       double* __restrict__ tinv, int* __restrict__ ticket) {
+       double* __restrict__ tinv, int* __restrict__ ticket, PivotCtl pc) {
     // ONE LDS array, re-used by the phases of a task:
     //   update:            X staging buffers Xs[2][32][80]
     //   diagonal task:     U[c][r], the updated block (POTRF / GETRF works on it)
@@ -848,32 +916,29 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     if (LU && is_diag) {
         __syncthreads();
         if (wave == 0) {
-        // no-pivot LU of the updated block (k_getrf_block's scheme): lane r holds row r, multipliers l(r,j) = a(r,j) / pivot
-        // with the reciprocal from v_rcp_f64 + two Newton steps (the IEEE divide sequence sits on the 64-step critical path)
+        // LU of the updated block (getrf_wave: lane r holds row r; threshold pivoting inside the block when pc.tol > 0, implicit
+        // interchanges), multipliers with the reciprocal from v_rcp_f64 + two Newton steps (the IEEE divide sequence sits on the
+        // 64-step critical path).  Rows are stored at their pivot positions.
         double a[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c) a[c] = U[c * ST_ULD + lane];
         bool bad = false;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double piv = readlane_f64(a[j], j);
-            bad = bad || !(piv != 0.0);
-            double rp = __builtin_amdgcn_rcp(piv);
-            rp = rp * (2.0 - piv * rp);
-            rp = rp * (2.0 - piv * rp);
-            const double l = (lane > j) ? a[j] * rp : 0.0;
-            if (lane > j) a[j] = l;
-#pragma unroll
-            for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_f64(a[c], j);
-        }
+        int np = 0;
+        const int pos = getrf_wave<true>(a, lane, b, pc.tol, pc.eps, bad, np);
         if (bad && lane == 0) atomicOr(info, 1);
+        if (np > 0 && lane == 0) atomicAdd(pc.nperturb, np);
         double* __restrict__ PUd = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             if (lane < b && c < b) {
-                if (c < lane) Ag[lane + (int64_t)c * ld] = a[c]; else PUd[c + (int64_t)lane * ld] = a[c];
+                if (c < pos) Ag[pos + (int64_t)c * ld] = a[c]; else PUd[c + (int64_t)pos * ld] = a[c];
             }
-            U[c * ST_ULD + lane] = a[c];        // the factored block (L below, U on and above the diagonal; identity padding)
+            U[c * ST_ULD + pos] = a[c];         // the factored block (L below, U on and above the diagonal; identity padding)
+        }
+        if (pc.pivpos && lane < b) {
+            const int g0 = t.first_col + t.diag;
+            pc.pivpos[g0 + lane] = g0 + pos;
+            pc.pivinv[g0 + pos] = g0 + lane;
         }
         }
         __syncthreads();
@@ -1017,6 +1082,34 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    if (LU && (t.mode & 1) && pc.pivinv) {
+        // U^T rows: the tile's 64 columns are the block's rows of U; the diagonal workgroup interchanged rows, so the columns
+        // are brought into pivot order (position p <- original column pivinv[p]).  Through LDS ([column][row] image), the
+        // accumulator layout is per-lane fixed.  Skipped (wave-uniform test) when the block kept its natural order.
+        const int g0 = t.first_col + t.diag;
+        int src[16];
+        bool ident = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cj = 16 * q + fk + 4 * r;
+                src[4 * q + r] = (cj < b) ? pc.pivinv[g0 + cj] - g0 : cj;
+                ident = ident && src[4 * q + r] == cj;
+            }
+        if (!__all(ident)) {            // per wave; the waves' rows are disjoint, so is their part of the LDS image
+            const int ci = 16 * wave + fr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) U[(16 * q + fk + 4 * r) * ST_ULD + ci] = rt[q][r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rt[q][r] = U[src[4 * q + r] * ST_ULD + ci];
+        }
+        __syncthreads();                // the image is overwritten by Dt / Tl below
+    }
     {
         // X <- R D^{-T} with MFMA only, per wave (its 16 rows are independent of the other waves'): for every 16-column
         // block q   X_q = R_q T_q^{-T}   (A operand = the block's inverse, B operand = R_q as it sits in the registers),
@@ -1098,10 +1191,10 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 }
 
 void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* flags, int epoch, int* info, double* tinv, int* ticket,
-                 hipStream_t st) {
+                 PivotCtl pc, hipStream_t st) {
     if (ntasks <= 0) return;
-    if (lu) hipLaunchKernelGGL(k_step<true>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv, ticket);
-    else hipLaunchKernelGGL(k_step<false>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv, ticket);
+    if (lu) hipLaunchKernelGGL(k_step<true>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv, ticket, pc);
+    else hipLaunchKernelGGL(k_step<false>, dim3(ntasks), dim3(256), 0, st, tasks, Lsx, flags, epoch, info, tinv, ticket, pc);
 }
 
 // ---------------------------------------------------------------------------------------------------

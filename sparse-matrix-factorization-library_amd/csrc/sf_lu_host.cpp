@@ -213,9 +213,14 @@ int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_st
 int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct gpu_info_struct* list,
                                      struct matrix_info_struct* mi) {   // L:2668-3573
     if (!common || !mi || !mi->Lsx) return SF_ERR_ARG;
+    // PivInv (LU/Include/info.h: the field of the reference's disabled static pre-pivot, L:589-673) carries the record of the
+    // in-block interchanges: PivInv[g] = row position of original row g (same 64-column block); identity when nothing moved
+    if (!mi->PivInv) mi->PivInv = (sf_long*)malloc((size_t)(mi->nrow > 0 ? mi->nrow : 1) * sizeof(sf_long));
+    if (!mi->PivInv) return SF_ERR_ALLOC;
+    for (sf_long j = 0; j < mi->nrow; ++j) mi->PivInv[j] = j;
     return sf_handlers_factorize(common, list, 1, mi->serial, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi,
                                  mi->Lsxp, mi->Lp, mi->Li, mi->isSymmetric ? nullptr : mi->Up, mi->isSymmetric ? nullptr : mi->Ui,
-                                 mi->Lx, mi->isSymmetric ? nullptr : mi->Ux, mi->Lsx);
+                                 mi->Lx, mi->isSymmetric ? nullptr : mi->Ux, mi->Lsx, mi->PivInv);
 }
 
 int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {
@@ -237,6 +242,18 @@ int SparseFrame_solve_supernodal(struct matrix_info_struct* mi) {
         const sf_long* rows = mi->Lsi + mi->Lsip[s];
         const double* P = mi->Lsx + mi->Lsxp[s];
         for (sf_long c = 0; c < nscol; ++c) {
+            if (mi->PivInv && c % 64 == 0) {
+                // the row interchanges of this 64-column block (restricted to its diagonal block), applied as the sweep
+                // reaches it: the L entries to the left of the block were stored at the rows' original places
+                const sf_long c0 = mi->Super[s] + c, bw = (nscol - c < 64) ? nscol - c : 64;
+                double tmp[64];
+                bool moved = false;
+                for (sf_long k = 0; k < bw; ++k) moved = moved || mi->PivInv[c0 + k] != c0 + k;
+                if (moved) {
+                    for (sf_long k = 0; k < bw; ++k) tmp[mi->PivInv[c0 + k] - c0] = x[c0 + k];
+                    for (sf_long k = 0; k < bw; ++k) x[c0 + k] = tmp[k];
+                }
+            }
             const double xj = x[rows[c]];
             const double* col = P + c * lda;
             for (sf_long r = c + 1; r < nsrow; ++r) x[rows[r]] -= col[r] * xj;

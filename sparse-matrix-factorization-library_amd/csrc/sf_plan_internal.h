@@ -103,6 +103,10 @@ struct sf_chol_plan {
     std::atomic<int> dl_error{0};
     std::atomic<size_t> dl_next_piece{0};
     double* dl_host = nullptr;                  // destination of the running download (reference layout)
+    // LU pivoting (sf_kernels.h, PivotCtl): threshold inside the 64 x 64 diagonal blocks, perturbation = piv_perturb * max|a_ij|
+    double piv_tol = 0.1, piv_perturb = 1.4901161193847656e-08 /* sqrt(eps) */, amax = 0;
+    int32_t* d_piv = nullptr;   // pivpos[n] | pivinv[n] | perturbation counter
+    int last_perturbed = 0;
     bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
     int64_t xC = 0;             // doubles in one set of nsrow x nscol panels (Cholesky: == xsize)
     int64_t unz = 0;            // LU: entries of U (by row)

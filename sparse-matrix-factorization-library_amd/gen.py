@@ -164,6 +164,19 @@ def unsymmetric_stencil(nx, ny=1, nz=1, extra_per_row=1, seed=2024, reach=1, dro
     return n, Cp, Ci, Cx
 
 
+def unsymmetric_general(nx, ny=1, nz=1, seed=7, reach=1, diag_scale=0.3):
+    """the stencil pattern of `unsymmetric_stencil`, NOT diagonally dominant: off-diagonals U(-1, 1), diagonal
+    diag_scale * U(-1, 1) * (number of entries in the row)^(1/2) -- a matrix that needs pivoting.  Whole matrix in CSC."""
+    n, Cp, Ci, Cx = unsymmetric_stencil(nx, ny, nz, extra_per_row=0, seed=seed, reach=reach, drop=0.1)
+    rng = np.random.default_rng(seed + 1)
+    Cx = rng.uniform(-1.0, 1.0, size=Cx.size)
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    isd = Ci == cols
+    cnt = np.bincount(Ci, minlength=n).astype(float)
+    Cx[isd] = diag_scale * rng.uniform(-1.0, 1.0, size=int(isd.sum())) * np.sqrt(cnt[Ci[isd]])
+    return n, Cp, Ci, Cx
+
+
 def dense_from_csc(n, Cp, Ci, Cx):
     A = np.zeros((n, n))
     for j in range(n):

@@ -44,15 +44,15 @@ int main() {
         for (int ti : {0, 1, 3, 7}) {
             std::vector<sf::StepTask> t;
             const int diag = 64 * ti;
-            t.push_back(sf::StepTask{0, 0, (int32_t)nsrow, 0, diag, 64, diag, 64, 0, 0, 0, 0});
-            for (int k = 0; k < ntiles; ++k) t.push_back(sf::StepTask{0, 0, (int32_t)nsrow, 0, diag, 64, 512 + 64 * k, 64, 0, 0, 0, 0});
+            t.push_back(sf::StepTask{0, 0, (int32_t)nsrow, 0, diag, 64, diag, 64, 0, 0, 0, 0, 0, 0});
+            for (int k = 0; k < ntiles; ++k) t.push_back(sf::StepTask{0, 0, (int32_t)nsrow, 0, diag, 64, 512 + 64 * k, 64, 0, 0, 0, 0, 0, 0});
             CK(hipMemcpy(dt, t.data(), t.size() * sizeof(sf::StepTask), hipMemcpyHostToDevice));
             const int reps = 20;
             CK(hipMemset(tickets, 0, 64 * sizeof(int)));
-            sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, tickets + reps, 0);
+            sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, tickets + reps, sf::PivotCtl{0, 0, nullptr, nullptr, nullptr}, 0);
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
-            for (int r = 0; r < reps; ++r) sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, tickets + r, 0);
+            for (int r = 0; r < reps; ++r) sf::launch_step(dt, (int)t.size(), 0, d, flags, ++epoch, info, tinv, tickets + r, sf::PivotCtl{0, 0, nullptr, nullptr, nullptr}, 0);
             CK(hipEventRecord(e1, 0));
             CK(hipDeviceSynchronize());
             float ms;
