@@ -152,11 +152,17 @@ __device__ __forceinline__ int getrf_wave(double (&a)[NB], int lane, int b, doub
     for (int j = 0; j < NB; ++j) {
         int p = j;
         if (tol > 0.0 && j < b) {               // wave-uniform: no pivot search when pivoting is off or in the padding
-            double m;
-            const int pm = wave_argmax_abs(a[j], active, &m);
+            // cheap test first: an upper bound of max |a_ij| from ONE reduction over the high words; the exact arg-max (a second
+            // reduction and a ballot) only when the natural row fails it
             const double nat = readlane_f64(a[j], j);
             const bool nat_free = ((__ballot(active) >> j) & 1ull) != 0;
-            if (!(nat_free && fabs(nat) >= tol * m && nat != 0.0) && pm >= 0) p = pm;
+            const uint32_t mhi = wave_max_u32(active ? (((uint32_t)__double2hiint(a[j]) & 0x7fffffffu) + 1u) : 0u);
+            const double m_ub = __hiloint2double((int)(mhi - 1u), -1);
+            if (!(nat_free && mhi != 0u && fabs(nat) >= tol * m_ub && nat != 0.0)) {
+                double m;
+                const int pm = wave_argmax_abs(a[j], active, &m);
+                if (!(nat_free && fabs(nat) >= tol * m && nat != 0.0) && pm >= 0) p = pm;
+            }
             p = __builtin_amdgcn_readfirstlane(p);
         }
         double piv = readlane_dyn_f64(a[j], p);

@@ -226,6 +226,7 @@ def test_lu_zero_pivot_is_reported():
     S = sf.analyze(n, Cp, Ci, Cx, None, 1 << 30, "lu", False)
     plan = sf.LUPlan(S)
     plan.set_values(S.Lx, S.Ux)
+    plan.set_pivoting(0.0, 0.0)          # the reference's behaviour: no pivoting, no perturbation
     with pytest.raises(sf.SparseFrameError, match="SF_ERR_NOT_POSDEF"):
         plan.factorize()
     plan.close()
