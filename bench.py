@@ -33,6 +33,87 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix; v_mfma_f64_16x16x4_f64 = 2048 flop / 64 cyc / SIMD
 
 
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (guide: 8 TB/s spec, ~6.3 TB/s achievable)
+
+
+def secondary_case(sf, np, kind, steps=3):
+    """one more BASELINE config timed in the same run (driver-side numbers for configs 3 and 5):
+    kind 'config3' = 2-D 1000x1000 21-point random SPD stencil (the HBM-/latency-bound extend-add config),
+    kind 'config5' = unsymmetric 19-point stencil 79^3, LU with threshold pivoting inside the diagonal blocks."""
+    t0 = time.time()
+    if kind == "config3":
+        M = 1000
+        n, Cp, Ci, Cx = sf.gen.stencil_spd_lower(M, M)
+        sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(M, M, 1, 3, 2), sf.REFERENCE_SLOT_1GPU)
+        plan = sf.CholPlan(sym)
+        plan.set_values(sym.Lx)
+        wl = "2D 1000x1000 grid, 21-point random SPD stencil (rng 12345), n = 1M, Cholesky fp64, geometric ND with 2-line separators"
+    else:
+        M = 79
+        n, Cp, Ci, Cx = sf.gen.unsymmetric_stencil(M, M, M, extra_per_row=0, seed=2024, drop=0.05)
+        sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False)
+        plan = sf.LUPlan(sym)
+        plan.set_values(sym.Lx, sym.Ux)
+        wl = ("unsymmetric 3D 19-point stencil 79^3 (5% of the entries dropped one-sidedly; SURVEY 8d's one random long-range entry "
+              "per row is not used: it destroys the grid separators and the fill explodes under a geometric ordering), diagonally "
+              "dominant, LU fp64 with threshold partial pivoting (tol 0.1) inside the 64x64 diagonal blocks")
+    t_setup = time.time() - t0
+    plan.factorize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.factorize(sync=False)
+    plan.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    plan.set_profiling(True)
+    plan.factorize(sync=True)
+    plan.set_profiling(False)
+    F = sym.flops_struct
+    out = {"workload": wl, "n": int(n), "nnz_input": int(len(Ci)), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
+           "F_struct": F, "ms_per_step": round(ms, 3), "GFLOPs": round(F / (ms * 1e-3) / 1e9, 1), "steps": steps,
+           "launches": int(plan.stat("launches")), "levels": int(plan.stat("levels")), "setup_s": round(t_setup, 2),
+           "kernel_ms": {"schur_gemm": round(plan.stat("last_update_ms"), 3), "schur_small": round(plan.stat("last_small_update_ms"), 3),
+                         "fused_step": round(plan.stat("last_step_ms"), 3), "outer_gemm": round(plan.stat("last_outer_gemm_ms"), 3),
+                         "potrf": round(plan.stat("last_potrf_ms"), 3), "trsm": round(plan.stat("last_trsm_ms"), 3),
+                         "load": round(plan.stat("last_load_ms"), 3)}}
+    x = plan.solve(1 + np.arange(n) / n)
+    out["device_solve_ms"] = round(plan.stat("last_solve_ms"), 3)
+    if kind == "config3":
+        out["residual_device_solve"] = sf.validate_solution(sym, x)
+        # HBM roofline of the whole factorization (SURVEY 8d): algorithmic bytes = memset + loadA (16 nnz + 8 xsize) + every
+        # panel read and written once by its factorization (16 xsize) + read once as an update source (8 xsize) + the fused
+        # scatter (16 B per scattered element)
+        E = plan.stat("scatter_elems")
+        alg = 8.0 * sym.xsize + 16.0 * sym.nnz + 8.0 * sym.xsize + 16.0 * sym.xsize + 8.0 * sym.xsize + 16.0 * E
+        gbs = alg / (ms * 1e-3) / 1e9
+        traffic, src = None, None
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_config3.json")))
+        if files:
+            with open(files[-1]) as f:
+                traffic = json.load(f).get("_total", {}).get("hbm_bytes_per_factorization")
+            src = "committed rocprofv3 --pmc passes: " + os.path.basename(files[-1])
+        out["roofline"] = {"bound": "hbm", "kernel": "whole factorization (level-scheduled: latency-bound, see DESIGN 5)",
+                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                           "algorithmic_bytes": alg, "scatter_elems": E, "traffic": traffic, "traffic_source": src}
+    else:
+        out["pivot_tol"] = plan.stat("pivot_tol")
+        out["perturbed_pivots"] = int(plan.stat("perturbed_pivots"))
+        out["rows_interchanged"] = int(np.count_nonzero(plan.get_pivots() != np.arange(n)))
+        # residual of the device solve against the permuted matrix (numpy, reference validate formula L:3702-3858)
+        lc = np.repeat(np.arange(n), np.diff(sym.Lp))
+        r = -(1 + np.arange(n) / n)
+        np.add.at(r, sym.Li, sym.Lx * x[lc])
+        ur = np.repeat(np.arange(n), np.diff(sym.Up))
+        off = sym.Ui != ur
+        np.add.at(r, ur[off], sym.Ux[off] * x[sym.Ui[off]])
+        colsum = np.zeros(n)
+        np.add.at(colsum, lc, np.abs(sym.Lx))
+        np.add.at(colsum, sym.Ui[off], np.abs(sym.Ux[off]))
+        out["residual_device_solve"] = float(np.abs(r).max() / (colsum.max() * np.abs(x).max() + 2.0))
+    plan.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,7 +122,10 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="N of the N^3 grid (default: 128 for cholesky = BASELINE config 2, 79 for lu = config 5)")
     ap.add_argument("--method", choices=["cholesky", "lu"], default="cholesky",
                     help="cholesky: 3-D 7-pt Laplacian (the headline workload); lu: unsymmetric 19-pt stencil, no-pivot LU")
-    ap.add_argument("--cpu-grid", type=int, default=72, help="N of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-grid", type=int, default=96,
+                    help="N of the CPU-baseline sample (0 = skip; 128 = the headline matrix itself, ~1.5 min: kept run in profiles/)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1 default workload: skip the extra lines for BASELINE configs 3 and 5 (out['secondary'])")
     ap.add_argument("--cpu-threads", type=int, default=0, help="BLAS threads of the CPU baseline (0 = min(cores,16))")
     ap.add_argument("--workload", choices=["lap3d", "stencil2d"], default="lap3d",
                     help="cholesky only: lap3d = N^3 7-point Laplacian (config 2); stencil2d = N x N grid, 21-point random SPD "
@@ -168,12 +252,12 @@ def main():
     value = F_struct * units / (elapsed / args.steps) / 1e9
 
     out = {
-        "metric": "numeric-factorization GFLOP/s (supernodal %s)" % ("no-pivot LU" if lu else "Cholesky"),
+        "metric": "numeric-factorization GFLOP/s (supernodal %s)" % ("LU, pivoting inside the diagonal blocks" if lu else "Cholesky"),
         "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if (sharded is not None and args.scale == "strong") else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"unsymmetric 3D 19-point stencil {N}^3 (5% of entries dropped one-sidedly), diagonally dominant, "
-                                f"no-pivot LU fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if lu else
+                                f"LU fp64 with threshold partial pivoting inside the 64x64 diagonal blocks, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if lu else
                                (f"2D {N}x{N} grid, 21-point random SPD stencil (rng 12345), Cholesky fp64, geometric ND with 2-line "
                                 f"separators, devSlotSize {sf.REFERENCE_SLOT_1GPU}") if args.workload == "stencil2d" else
                                f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
@@ -187,7 +271,9 @@ def main():
                                   ("1 matrix per GPU (independent)" if ngpu > 1 else "single GPU"),
                    "sharding": sharded.plan_info() if sharded is not None else None,
                    "exec_GFLOPs": round(F_exec * units / (elapsed / args.steps) / 1e9, 2),
-                   "host_analyze_s": round(t_analyze, 2), "plan_create_s": round(t_plan, 2)},
+                   "host_analyze_s": round(t_analyze, 2), "plan_create_s": round(t_plan, 2),
+                   "timed_region": "numeric factorization only (memset + assembly + panels + Schur updates) on resident inputs; the H2D of "
+                                   "the matrix values (8 B x nnz_input) and the factor's D2H are excluded -- see pcie_inclusive"},
     }
 
     if rank == 0 and not args.no_roofline and sharded is None:
@@ -210,6 +296,8 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<1> (Schur update, fused scatter%s)" % (", L and U^T sides" if lu else ""),
                            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "traffic_source": ("committed rocprofv3 --pmc passes (profiles/), NOT measured in this run: "
+                                              + os.path.basename(files[-1])) if traffic is not None else None,
                            "traffic_note": "HBM bytes per launch of k_gemm<1> from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                            "(profiles/, FETCH_SIZE x2 after calibration); null when no committed pass matches",
                            "kernel_ms": round(upd_ms, 3), "panel_ms": round(plan.stat("last_panel_ms"), 3),
@@ -286,17 +374,29 @@ def main():
         out["config"]["residual"] = res
         del Lsx
 
+    if rank == 0 and ngpu == 1 and not args.no_secondary and not lu and args.workload == "lap3d" and args.grid in (0, 128):
+        out["secondary"] = {"config3": secondary_case(sf, np, "config3"), "config5": secondary_case(sf, np, "config5")}
+
     if rank == 0 and ngpu == 1 and args.cpu_grid > 0:
         import oracle
         threads = args.cpu_threads or min(os.cpu_count() or 1, 16)   # reference: min(omp_max, 16), SparseFrame.c:3357
         binfo = oracle.blas_init("auto", threads=threads)
         M = min(args.cpu_grid, 56) if lu else (N if args.workload == "stencil2d" else args.cpu_grid)
-        n2, sym2, _ = make(M)
         cpu_factorize = oracle.lu_factorize if lu else oracle.chol_factorize
-        cpu_factorize(sym2)   # warm-up: first-touch page faults dominated the reference probe
+        # warm-up (BLAS thread pool, allocator) on a small case of the same kind, then ONE timed factorization of the sample
+        # (cpu-grid 128 = the headline matrix itself)
+        if M > 56 and args.workload != "stencil2d":
+            _, symw, _ = make(40)
+            cpu_factorize(symw)
+        n2, sym2, _ = make(M) if M != N else (n, sym, nnz_in)
+        if M <= 56 or args.workload == "stencil2d":
+            cpu_factorize(sym2)
         _, info, st = cpu_factorize(sym2)
         out["cpu_baseline"] = {"value": round(sym2.flops_struct / st["seconds"] / 1e9, 2), "unit": "GFLOP/s",
-                               "cores": int(binfo["threads"]), "kind": "port",
+                               "cores": int(binfo["threads"]), "host_cores": int(os.cpu_count() or 0),
+                               "seconds": round(st["seconds"], 2),
+                               "gpu_over_cpu_same_metric": round(value / (sym2.flops_struct / st["seconds"] / 1e9), 1),
+                               "kind": "port",
                                "sample": f"{'unsymmetric 19-point stencil' if lu else ('2D 21-point stencil' if args.workload == 'stencil2d' else '3D 7-point Laplacian')} grid {M} (same generator and ordering), full numeric "
                                          f"factorization, F_struct {sym2.flops_struct:.3e}, {st['seconds']:.2f} s, "
                                          f"1 tree worker x {binfo['threads']} BLAS threads, "

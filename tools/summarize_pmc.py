@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sum rocprofv3 --pmc counter_collection.csv files per kernel -> the JSON kept under profiles/.
 
-usage: summarize_pmc.py OUT.json DIR [DIR ...]     (each DIR = one rocprofv3 -d directory, one pass each)
+usage: summarize_pmc.py [--factorizations K] [--what TEXT] OUT.json DIR [DIR ...]     (each DIR = one rocprofv3 -d directory, one pass each)
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE reads half of the bytes for this code's 8-byte-per-lane
 loads (tools/fetch_calib.hip: 4 GiB read -> 2,097,163.6 KiB), so fetch bytes = 2 * FETCH_SIZE * 1024.
@@ -26,7 +26,16 @@ def short(name):
 
 
 def main():
-    out, dirs = sys.argv[1], sys.argv[2:]
+    argv = sys.argv[1:]
+    nfact, what = 1, None
+    while argv and argv[0].startswith("--"):
+        if argv[0] == "--factorizations":
+            nfact = int(argv[1]); argv = argv[2:]
+        elif argv[0] == "--what":
+            what = argv[1]; argv = argv[2:]
+        else:
+            raise SystemExit("unknown option " + argv[0])
+    out, dirs = argv[0], argv[1:]
     acc = defaultdict(lambda: defaultdict(float))
     launches = defaultdict(lambda: defaultdict(set))
     for d in dirs:
@@ -52,6 +61,11 @@ def main():
         if "SQ_BUSY_CYCLES" in acc[k] and "SQ_VALU_MFMA_BUSY_CYCLES" in acc[k] and acc[k]["SQ_BUSY_CYCLES"] > 0:
             e["mfma_busy_over_sq_busy"] = acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / acc[k]["SQ_BUSY_CYCLES"]
         res[k] = e
+    if what:
+        res["_what"] = what
+    tot = sum(e.get("hbm_bytes_total", 0.0) for k, e in res.items() if isinstance(e, dict) and not k.startswith("_") and k != "calibration")
+    res["_total"] = {"factorizations_in_the_run": nfact, "hbm_bytes_per_factorization": tot / nfact,
+                     "note": "sum over all kernels of (2 x FETCH_SIZE + WRITE_SIZE) x 1024, divided by the factorizations in the profiled run"}
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
