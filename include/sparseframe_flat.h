@@ -167,6 +167,17 @@ int sf_chol_plan_create_distributed(sf_chol_plan **plan, int device, sf_long n, 
                                     const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                                     const sf_long *Lp, const sf_long *Li, const int32_t *phase, int load_top,
                                     int rank, int nranks);
+/* PROPORTIONAL MAPPING of the top: rank `rank`'s plan straight from the owner map of
+ * sf_subtree_partition[_weighted].  A top supernode belongs to the GROUP of ranks whose subtrees lie below it: only they
+ * store its panel, split its GEMMs and sum its block columns (a sub-communicator per group), and the groups of one level
+ * work concurrently.  A rank stores its own subtrees plus the top supernodes on its path to the root instead of the
+ * whole top.  Run with sf_chol_plan_factorize_distributed (it creates the sub-communicators on first use). */
+int sf_chol_plan_create_mapped(sf_chol_plan **plan, int device, sf_long n, sf_long nsuper,
+                               const sf_long *Super, const sf_long *SuperMap,
+                               const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                               const sf_long *Lp, const sf_long *Li, const int32_t *owner, int rank, int nranks);
+/* bit r set = rank r takes part in the all-reduce of segment k */
+uint32_t sf_chol_plan_segment_group(const sf_chol_plan *plan, sf_long k);
 sf_long sf_chol_plan_num_segments(const sf_chol_plan *plan);
 /* offsets/counts may be NULL to query *nregions only */
 int sf_chol_plan_segment_regions(const sf_chol_plan *plan, sf_long k, sf_long capacity, sf_long *nregions,
@@ -213,6 +224,11 @@ int sf_lu_plan_create_distributed(sf_lu_plan **plan, int device, sf_long n, sf_l
                                   const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                                   const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
                                   const int32_t *phase, int load_top, int rank, int nranks);
+int sf_lu_plan_create_mapped(sf_lu_plan **plan, int device, sf_long n, sf_long nsuper,
+                             const sf_long *Super, const sf_long *SuperMap,
+                             const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                             const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
+                             const int32_t *owner, int rank, int nranks);
 int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *Ux /* NULL if U aliases L */);
 /* Pivoting (BASELINE config 5 asks for it, the reference has none: magma_dgetrf_nopiv L:2653, devIpiv = NULL
  * L:3344, static pre-pivot L:589-673 disabled).  The symbolic structure is static, so rows can only be exchanged where that

@@ -106,6 +106,14 @@ lib.sf_subtree_partition_weighted.restype = C.c_int
 lib.sf_chol_plan_create_distributed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7 + \
     [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int]
 lib.sf_chol_plan_create_distributed.restype = C.c_int
+lib.sf_chol_plan_create_mapped.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7 + \
+    [C.POINTER(C.c_int32), C.c_int, C.c_int]
+lib.sf_chol_plan_create_mapped.restype = C.c_int
+lib.sf_lu_plan_create_mapped.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9 + \
+    [C.POINTER(C.c_int32), C.c_int, C.c_int]
+lib.sf_lu_plan_create_mapped.restype = C.c_int
+lib.sf_chol_plan_segment_group.argtypes = [C.c_void_p, C.c_int64]
+lib.sf_chol_plan_segment_group.restype = C.c_uint32
 lib.sf_chol_plan_num_segments.argtypes = [C.c_void_p]
 lib.sf_chol_plan_num_segments.restype = C.c_int64
 lib.sf_chol_plan_segment_regions.argtypes = [C.c_void_p, C.c_int64, C.c_int64, c_long_p, c_long_p, c_long_p]

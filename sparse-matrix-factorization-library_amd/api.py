@@ -214,6 +214,10 @@ class _ShardedPlanMixin:
     def num_segments(self):
         return int(lib.sf_chol_plan_num_segments(self._h))
 
+    def segment_group(self, k):
+        """bit mask of the ranks that sum segment k's block columns"""
+        return int(lib.sf_chol_plan_segment_group(self._h, k))
+
     def segment_regions(self, k):
         """[(offset, count)] in doubles relative to factor_device_ptr: regions to sum over the ranks before segment k"""
         nr = C.c_int64()
@@ -255,10 +259,17 @@ class CholPlan(_ShardedPlanMixin):
     rank/nranks (with phase): distributed top (sf_chol_plan_create_distributed), run with factorize_phase(0) and then
     factorize_segment(k) after summing segment_regions(k) over the ranks."""
 
-    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1):
+    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1, owner=None):
+        """owner (with rank / nranks): the owner map of subtree_partition -> proportionally mapped plan
+        (sf_chol_plan_create_mapped): own subtrees + the top supernodes above them, groups of ranks per top supernode"""
         h = C.c_void_p()
         self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
-        if phase is None:
+        if owner is not None:
+            owner = np.ascontiguousarray(owner, dtype=np.int32)
+            check(lib.sf_chol_plan_create_mapped(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
+                                                 owner.ctypes.data_as(C.POINTER(C.c_int32)), int(rank), int(nranks)),
+                  "sf_chol_plan_create_mapped")
+        elif phase is None:
             check(lib.sf_chol_plan_create(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep]),
                   "sf_chol_plan_create")
         elif nranks <= 1:
@@ -328,7 +339,7 @@ class LUPlan(_ShardedPlanMixin):
     """Device-resident supernodal no-pivot LU (flat ABI, sf_lu_plan_*).  `sym` comes from analyze(..., method='lu').
     phase/load_top/rank/nranks: distributed multi-GPU plan (sf_lu_plan_create_distributed), as CholPlan."""
 
-    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1):
+    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1, owner=None):
         if not sym.lu:
             raise ValueError("LUPlan needs an LU symbolic analysis (method='lu')")
         h = C.c_void_p()
@@ -337,7 +348,12 @@ class LUPlan(_ShardedPlanMixin):
         if not self._alias:
             self._keep += [sym.Up, sym.Ui]
         args = [_lp(a) for a in self._keep] + ([None, None] if self._alias else [])
-        if phase is None:
+        if owner is not None:
+            owner = np.ascontiguousarray(owner, dtype=np.int32)
+            check(lib.sf_lu_plan_create_mapped(C.byref(h), device, sym.n, sym.nsuper, *args,
+                                               owner.ctypes.data_as(C.POINTER(C.c_int32)), int(rank), int(nranks)),
+                  "sf_lu_plan_create_mapped")
+        elif phase is None:
             check(lib.sf_lu_plan_create(C.byref(h), device, sym.n, sym.nsuper, *args), "sf_lu_plan_create")
         else:
             phase = np.ascontiguousarray(phase, dtype=np.int32)

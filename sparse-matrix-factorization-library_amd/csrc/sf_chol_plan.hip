@@ -97,10 +97,14 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                        const sf_long* Super, const sf_long* SuperMap,
                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                        const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
-                       const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1) {
+                       const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1,
+                       const uint32_t* top_mask = nullptr) {
+    // top_mask[s] (phase-1 supernodes, optional): bit r set = rank r takes part in supernode s (proportional mapping: the
+    // ranks whose subtrees lie below s).  Its panel exists only on those ranks, their GEMM shares and the all-reduce run
+    // inside that group.  Without it every rank takes part in every top supernode.
     if (!out) return SF_ERR_ARG;
     *out = nullptr;
-    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !phase_in)) return SF_ERR_ARG;
+    if (nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks || (nranks > 1 && !phase_in)) return SF_ERR_ARG;
     if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
     if (n >= (sf_long)0x7fffffff) return SF_ERR_ARG;   // device row indices are 32-bit
     int ndev = 0;
@@ -133,6 +137,24 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             if (phase_in[s] < -1 || phase_in[s] > 1) { delete p; return SF_ERR_ARG; }
             p->phase[s] = (int8_t)phase_in[s];
         }
+    // group of every top supernode stored here: mask, this rank's index in it and its size
+    const uint32_t all_ranks = nranks >= 32 ? 0xffffffffu : ((1u << nranks) - 1u);
+    std::vector<uint32_t> gmask(nsuper, 0);
+    for (sf_long s = 0; s < nsuper; ++s) {
+        if (p->phase[s] != 1) continue;
+        const uint32_t m = (top_mask && nranks > 1) ? (top_mask[s] & all_ranks) : all_ranks;
+        if (!((m >> rank) & 1u)) { delete p; return SF_ERR_ARG; }      // a stored top supernode must list this rank
+        gmask[s] = m;
+    }
+    if (top_mask && nranks > 1) {
+        for (sf_long s = 0; s < nsuper; ++s)
+            if (top_mask[s] & all_ranks) p->all_masks.push_back(top_mask[s] & all_ranks);
+        std::sort(p->all_masks.begin(), p->all_masks.end());
+        p->all_masks.erase(std::unique(p->all_masks.begin(), p->all_masks.end()), p->all_masks.end());
+    } else if (nranks > 1) {
+        p->all_masks.push_back(all_ranks);
+    }
+    auto group_idx = [&](uint32_t m) { return __builtin_popcount(m & ((1u << rank) - 1u)); };
     std::vector<int64_t> XP(nsuper + 1, -1);
     {
         int64_t run = 0;
@@ -148,7 +170,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     p->h_XP = XP;
     for (sf_long s = 0; s < nsuper; ++s)
         if (p->phase[s] != 0) p->partial = true;
-    if (!load_top) p->partial = true;
+    if (load_top != 1) p->partial = true;
     const int64_t ushift = p->xC;     // PU(s) = PL(s) + ushift
 
     // ---------------- validate the structure the kernels index with ----------------
@@ -234,6 +256,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     for (sf_long s = 0; s < nsuper; ++s) blk_first[s + 1] = blk_first[s] + (Super[s + 1] - Super[s] + sf::OUTER_NB - 1) / sf::OUTER_NB;
     std::vector<size_t> blk_ready(blk_first[nsuper], 0);
 
+    int su_maxk = sf::SU_MAXK;              // SF_SU_MAXK: experiment knob
+    if (const char* env = getenv("SF_SU_MAXK")) su_maxk = atoi(env);
     int32_t n_flags = 0;
     int64_t max_diag_tasks = 0;     // k_step launches: scratch for the 16 x 16 inverses, 1024 doubles per diagonal task
     // steps of up to this many workgroups run as ONE k_step launch; beyond it (swarms of tiny panels at the bottom levels)
@@ -245,14 +269,38 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // stay covered by the tests
     int64_t fuse_max = 32 * sf::GEMM_GRID;
     if (const char* env = getenv("SF_FUSE_MAX")) fuse_max = strtoll(env, nullptr, 10);
+    // The sweep: one set of independent supernodes at a time -- phase 0: a level of the owned subtrees; phase 1: the top
+    // supernodes of one level that share one group of ranks (ascending mask: every rank meets the sets it shares with
+    // another rank in the same order, so the groups' collectives cannot wait for each other in a circle).
+    struct LevelSet { int ph; std::vector<sf_long> sn; uint32_t mask; int share_idx, share_cnt; };
+    std::vector<LevelSet> sets;
     for (int ph = 0; ph < 2; ++ph) {
-    if (ph == 1) p->launch_split = p->launches.size();
-    std::vector<std::vector<sf_long>> by_level(nlevels);
-    for (sf_long s = 0; s < nsuper; ++s)
-        if (p->phase[s] == ph) by_level[level[s]].push_back(s);
-    for (int l = 0; l < nlevels; ++l) {
-        const std::vector<sf_long>& Sl = by_level[l];
-        if (Sl.empty()) continue;
+        std::vector<std::vector<sf_long>> by_level(nlevels);
+        for (sf_long s = 0; s < nsuper; ++s)
+            if (p->phase[s] == ph) by_level[level[s]].push_back(s);
+        for (int l = 0; l < nlevels; ++l) {
+            if (by_level[l].empty()) continue;
+            if (ph == 0) { sets.push_back(LevelSet{0, by_level[l], 0, 0, 1}); continue; }
+            std::vector<uint32_t> ms;
+            for (sf_long s : by_level[l]) ms.push_back(gmask[s]);
+            std::sort(ms.begin(), ms.end());
+            ms.erase(std::unique(ms.begin(), ms.end()), ms.end());
+            for (uint32_t m : ms) {
+                LevelSet LS{1, {}, m, group_idx(m), __builtin_popcount(m)};
+                for (sf_long s : by_level[l])
+                    if (gmask[s] == m) LS.sn.push_back(s);
+                sets.push_back(std::move(LS));
+            }
+        }
+    }
+    p->launch_split = 0;
+    bool split_set = false;
+    for (const LevelSet& LS : sets) {
+    const int ph = LS.ph;
+    if (ph == 1 && !split_set) { p->launch_split = p->launches.size(); split_set = true; }
+    {
+        const std::vector<sf_long>& Sl = LS.sn;
+        const bool shared = ph == 1 && nranks > 1;          // additive updates split over the group, block columns reduced
         sf_long maxcol = 0;
         for (sf_long s : Sl) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
         // Two-level blocking of the in-panel factorization.  Outer block columns of OUTER_NB columns are
@@ -287,13 +335,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 }
                 if ((int64_t)gtasks.size() > g0) {
                     p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
-                    p->launches.back().split = (ph == 1 && nranks > 1);
+                    p->launches.back().split = shared && LS.share_cnt > 1;
+                    p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
                 }
             }
-            if (ph == 1 && nranks > 1) {
-                // reduce point: block column jo of every panel of the level is complete up to the sum over the ranks
+            if (shared) {
+                // reduce point: block column jo of every panel of the set is complete up to the sum over the group's ranks
                 if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
                 Segment sg;
+                sg.mask = LS.mask;
                 sg.l0 = p->launches.size();
                 for (sf_long s : Sl) {
                     const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
@@ -443,7 +493,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     g.c_off = XP[a] + (side ? ushift : 0);
                     g.strict = (lu && !side) ? 1 : 0;
                     probs.push_back(g);
-                    if (g.K <= sf::SU_MAXK) {
+                    if (g.K <= su_maxk) {
                         // short inner dimension: one wave per 64 x 32 tile (k_update_small); tiles entirely above the diagonal are skipped
                         const int tmn = (g.M + sf::SU_TM - 1) / sf::SU_TM, tnn = (g.N + sf::SU_TN - 1) / sf::SU_TN;
                         for (int tn = 0; tn < tnn; ++tn)
@@ -459,7 +509,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 const double fl = lu ? (2.0 * (double)dnm * dn * nk + 2.0 * (double)(dnm - dn) * dn * nk)
                                      : ((double)dn * (dn + 1) * nk + 2.0 * (double)(dnm - dn) * dn * nk);
                 p->flops_update += fl;
-                if (g.K <= sf::SU_MAXK) { p->flops_update_small += fl; level_small_flops += fl; }
+                if (g.K <= su_maxk) { p->flops_update_small += fl; level_small_flops += fl; }
                 p->flops_exec += fl;
                 p->scatter_elems += lu ? ((double)dnm * dn + (double)(dnm - dn) * dn)
                                        : ((double)dn * (dn + 1) / 2.0 + (double)(dnm - dn) * dn);
@@ -469,15 +519,18 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         if ((int64_t)gtasks.size() > g0) {
             p->launches.push_back(Launch{3, g0, (int)(gtasks.size() - g0)});
-            p->launches.back().split = (ph == 1 && nranks > 1);
+            p->launches.back().split = shared && LS.share_cnt > 1;
+            p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
         }
         if ((int64_t)stasks.size() > s0) {
             p->launches.push_back(Launch{6, s0, (int)(stasks.size() - s0)});
-            p->launches.back().split = (ph == 1 && nranks > 1);
+            p->launches.back().split = shared && LS.share_cnt > 1;
+            p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
             p->launches.back().flops = level_small_flops;
         }
     }
-    }   // phases
+    }   // level sets
+    if (!split_set) p->launch_split = p->launches.size();
     if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
     p->n_gemm_tasks = (int64_t)gtasks.size() + (int64_t)stasks.size();
 
@@ -550,7 +603,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (const char* env = getenv("SF_DL_SLOT_MB")) p->dl_slot = (int64_t)std::max(1, atoi(env)) << 17;
         const int64_t DL_SLOT = p->dl_slot;
         std::vector<DlPiece> runs;
+        std::vector<uint32_t> run_mask;
         int last_phase = -2;
+        uint32_t last_mask = 0;
         for (sf_long s = 0; s < nsuper; ++s) {
             if (XP[s] < 0) continue;
             const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
@@ -558,7 +613,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             for (int64_t jo = 0; jo * sf::OUTER_NB < nscol; ++jo) {
                 const int64_t J = jo * sf::OUTER_NB, w = std::min<int64_t>(sf::OUTER_NB, nscol - J);
                 DlPiece pc{XP[s] + J * nsrow, Lsxp[s] + J * hld, w * hld, blk_ready[blk_first[s] + jo], 0};
-                const bool can_merge = !runs.empty() && last_phase == p->phase[s] &&
+                const bool can_merge = !runs.empty() && last_phase == p->phase[s] && last_mask == gmask[s] &&
                                        runs.back().host_off + runs.back().count == pc.host_off &&
                                        (lu || runs.back().dev_off + runs.back().count == pc.dev_off) &&
                                        runs.back().count + pc.count <= DL_SLOT;
@@ -568,13 +623,23 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 } else {
                     pc.ev = p->phase[s];        // phase kept here until the pieces are dealt out below
                     runs.push_back(pc);
+                    run_mask.push_back(gmask[s]);
                 }
                 last_phase = p->phase[s];
+                last_mask = gmask[s];
             }
         }
-        int64_t top_seen = 0;
-        for (const DlPiece& r : runs) {
-            if (r.ev == 1 && nranks > 1 && (top_seen++ % nranks) != rank) continue;
+        std::vector<std::pair<uint32_t, int64_t>> seen_by_mask;     // pieces of a group's panels are dealt out inside the group
+        for (size_t ri = 0; ri < runs.size(); ++ri) {
+            const DlPiece& r = runs[ri];
+            if (r.ev == 1 && nranks > 1) {
+                const uint32_t m = run_mask[ri];
+                size_t k = 0;
+                while (k < seen_by_mask.size() && seen_by_mask[k].first != m) ++k;
+                if (k == seen_by_mask.size()) seen_by_mask.push_back({m, 0});
+                const int64_t seq = seen_by_mask[k].second++;
+                if ((int)(seq % __builtin_popcount(m)) != group_idx(m)) continue;
+            }
             for (int64_t o = 0; o < r.count; o += DL_SLOT)
                 p->dl_pieces.push_back(DlPiece{r.dev_off + o, r.host_off + o, std::min(DL_SLOT, r.count - o), r.ready, 0});
         }
@@ -668,7 +733,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         if (p->partial) {
             std::vector<int8_t> mask(std::max<sf_long>(nsuper, 1), 0);
-            for (sf_long s = 0; s < nsuper; ++s) mask[s] = (p->phase[s] == 0 || (p->phase[s] == 1 && load_top)) ? 1 : 0;
+            // the matrix entries of a shared top panel enter the sum once: on the first rank of its group (load_top == 2),
+            // or on the rank the caller names (load_top 0 / 1: the older interface, one group of all ranks)
+            for (sf_long s = 0; s < nsuper; ++s)
+                mask[s] = (p->phase[s] == 0 || (p->phase[s] == 1 && (load_top == 2 ? group_idx(gmask[s]) == 0 : load_top != 0))) ? 1 : 0;
             if ((rc = upload(&p->d_loadmask, mask, &p->bytes_device))) break;
         }
         if (lu) {
@@ -719,6 +787,56 @@ int sf_chol_plan_create_distributed(sf_chol_plan** out, int device, sf_long n, s
                                     int rank, int nranks) {
     return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, phase, load_top,
                        rank, nranks);
+}
+
+// Rank `rank`'s plan of an nranks-way factorization from the owner map of sf_subtree_partition* (owner[s] = rank of the
+// subtree holding s, -1 = top): PROPORTIONAL MAPPING of the top -- a top supernode belongs to the ranks whose subtrees lie
+// below it, only they store its panel, split its GEMMs and sum its block columns.
+static int create_mapped(sf_chol_plan** out, int device, bool lu, sf_long n, sf_long nsuper,
+                         const sf_long* Super, const sf_long* SuperMap, const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                         const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
+                         const int32_t* owner, int rank, int nranks) {
+    if (!out || !owner || nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks) return SF_ERR_ARG;
+    if (nsuper < 0 || !Super || !Lsip || (nsuper > 0 && (!SuperMap || !Lsi))) return SF_ERR_ARG;
+    std::vector<uint32_t> mask(std::max<sf_long>(nsuper, 1), 0);
+    std::vector<int32_t> phase(std::max<sf_long>(nsuper, 1), 0);
+    for (sf_long s = 0; s < nsuper; ++s) {
+        if (owner[s] < -1 || owner[s] >= nranks) return SF_ERR_ARG;
+        if (owner[s] >= 0) mask[s] |= 1u << owner[s];
+        const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        if (nscol < nsrow) {        // parents follow their children in the postorder
+            const sf_long row = Lsi[Lsip[s] + nscol];
+            if (row < 0 || row >= n) return SF_ERR_ARG;
+            const sf_long par = SuperMap[row];
+            if (par <= s || par >= nsuper) return SF_ERR_ARG;
+            mask[par] |= mask[s];
+        }
+    }
+    for (sf_long s = 0; s < nsuper; ++s) {
+        if (owner[s] >= 0) { phase[s] = owner[s] == rank ? 0 : -1; mask[s] = 0; }
+        else phase[s] = ((mask[s] >> rank) & 1u) ? 1 : -1;
+    }
+    return plan_create(out, device, lu, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, phase.data(), 2, rank, nranks, mask.data());
+}
+
+int sf_chol_plan_create_mapped(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
+                               const sf_long* Super, const sf_long* SuperMap,
+                               const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                               const sf_long* Lp, const sf_long* Li, const int32_t* owner, int rank, int nranks) {
+    return create_mapped(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, owner, rank, nranks);
+}
+
+int sf_lu_plan_create_mapped(sf_lu_plan** out, int device, sf_long n, sf_long nsuper,
+                             const sf_long* Super, const sf_long* SuperMap,
+                             const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                             const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
+                             const int32_t* owner, int rank, int nranks) {
+    return create_mapped(out, device, true, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, owner, rank, nranks);
+}
+
+// the group of ranks that sums segment k's block columns (bit r = rank r); 0 for a plan that is not distributed
+uint32_t sf_chol_plan_segment_group(const sf_chol_plan* p, sf_long k) {
+    return (p && k >= 0 && k < (sf_long)p->segments.size()) ? p->segments[k].mask : 0u;
 }
 
 int sf_lu_plan_create(sf_lu_plan** out, int device, sf_long n, sf_long nsuper,
@@ -857,7 +975,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, pc.pivinv, st); break;
             case 6: {       // k_update_small; a split launch (distributed top): this rank's share of the tiles (the update is a sum)
                 int64_t lo = 0, hi = L.count;
-                if (L.split) { lo = (int64_t)L.count * p->rank / p->nranks; hi = (int64_t)L.count * (p->rank + 1) / p->nranks; }
+                if (L.split) { lo = (int64_t)L.count * L.share_idx / L.share_cnt; hi = (int64_t)L.count * (L.share_idx + 1) / L.share_cnt; }
                 sf::launch_update_small(p->d_probs, p->d_stasks + L.first + lo, (int)(hi - lo), p->d_Lsx, p->d_relmap, st);
                 break;
             }
@@ -870,8 +988,8 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             case 4: {
                 uint32_t u0 = 0, u1 = L.units;
                 if (L.split) {
-                    u0 = (uint32_t)((uint64_t)L.units * (uint64_t)p->rank / (uint64_t)p->nranks);
-                    u1 = (uint32_t)((uint64_t)L.units * (uint64_t)(p->rank + 1) / (uint64_t)p->nranks);
+                    u0 = (uint32_t)((uint64_t)L.units * (uint64_t)L.share_idx / (uint64_t)L.share_cnt);
+                    u1 = (uint32_t)((uint64_t)L.units * (uint64_t)(L.share_idx + 1) / (uint64_t)L.share_cnt);
                 }
                 sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, u0, u1,
                                 L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, st);

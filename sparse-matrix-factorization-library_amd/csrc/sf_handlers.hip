@@ -151,14 +151,11 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
         th.emplace_back([&, r] {
             int rc = SF_OK;
             sf_chol_plan*& plan = entry->plans[r];
-            if (!plan) {
-                std::vector<int32_t> phase(nsuper);
-                for (sf_long s = 0; s < nsuper; ++s) phase[s] = owner[s] == r ? 0 : (owner[s] < 0 ? 1 : -1);
-                rc = lu ? sf_lu_plan_create_distributed(&plan, list[r].gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp,
-                                                        Lp, Li, Up, Ui, phase.data(), r == 0, r, N)
-                        : sf_chol_plan_create_distributed(&plan, list[r].gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp,
-                                                          Lp, Li, phase.data(), r == 0, r, N);
-            }
+            if (!plan)      // proportional mapping: own subtrees + the top supernodes above them
+                rc = lu ? sf_lu_plan_create_mapped(&plan, list[r].gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp,
+                                                   Lp, Li, Up, Ui, owner.data(), r, N)
+                        : sf_chol_plan_create_mapped(&plan, list[r].gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp,
+                                                     Lp, Li, owner.data(), r, N);
             if (!rc) rc = lu ? sf_lu_plan_set_values(plan, Lx, Ux) : sf_chol_plan_set_values(plan, Lx);
             // a rank without a usable plan cannot take part in the collectives; the others would wait for it, so plan
             // creation is checked by all ranks before any of them starts (below)

@@ -35,6 +35,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
@@ -57,9 +58,10 @@ RcclApi& rccl() {
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
         api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.handle, "ncclCommInitAll");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+        api.CommSplit = (decltype(api.CommSplit))dlsym(api.handle, "ncclCommSplit");
         api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
         api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
-        api.ok = api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.AllReduce && api.GetErrorString;
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.CommSplit && api.AllReduce && api.GetErrorString;
         if (!api.ok) fprintf(stderr, "[sparseframe-hip] librccl.so.1 lacks an expected entry point\n");
     });
     return api;
@@ -88,6 +90,7 @@ struct LocalGroup {
     hipEvent_t ev_sum = nullptr;
     int refs = 0;
     bool failed = false;
+    std::vector<std::pair<uint32_t, LocalGroup*>> children;      // sub-groups by rank mask (guarded by mu)
     void barrier() {
         std::unique_lock<std::mutex> g(mu);
         const uint64_t gen = generation;
@@ -115,6 +118,9 @@ struct sf_comm {
     int device = 0;
     ncclComm_t nccl = nullptr;
     LocalGroup* local = nullptr;
+    // sub-communicators of the groups of a proportionally mapped factorization, by the mask of WORLD ranks they hold
+    std::vector<std::pair<uint32_t, sf_comm*>> subs;
+    bool groups_ready = false;
 };
 
 namespace {
@@ -160,6 +166,20 @@ int local_allreduce(sf_comm* c, double* buf, int64_t count, hipStream_t st) {
 
 }  // namespace
 
+static LocalGroup* new_local_group(int n, int device) {
+    LocalGroup* G = new (std::nothrow) LocalGroup();
+    if (!G) return nullptr;
+    G->n = n;
+    G->refs = n;
+    bool ok = hipSetDevice(device) == hipSuccess && hipEventCreateWithFlags(&G->ev_sum, hipEventDisableTiming) == hipSuccess;
+    for (int r = 0; r < n; ++r) {
+        ok = ok && hipEventCreateWithFlags(&G->ev_ready[r], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&G->ev_done[r], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { delete G; return nullptr; }
+    return G;
+}
+
 // used by the handlers (sf_handlers.hip): communicators of all ranks of one process at once
 int sf_comm_create_all(sf_comm** comms, int nranks, const int* devices) {
     if (!comms || nranks < 1 || nranks > LOCAL_MAX || !devices) return SF_ERR_ARG;
@@ -172,17 +192,8 @@ int sf_comm_create_all(sf_comm** comms, int nranks, const int* devices) {
     for (int r = 0; r < nranks; ++r) comms[r] = nullptr;
     if (nranks > 1 && !same_device && !distinct) return SF_ERR_ARG;     // a mix of shared and own devices is not supported
     if (same_device) {
-        LocalGroup* G = new (std::nothrow) LocalGroup();
-        if (!G) return SF_ERR_ALLOC;
-        G->n = nranks;
-        G->refs = nranks;
-        HIP_TRY(hipSetDevice(devices[0]));
-        bool ok = hipEventCreateWithFlags(&G->ev_sum, hipEventDisableTiming) == hipSuccess;
-        for (int r = 0; r < nranks; ++r) {
-            ok = ok && hipEventCreateWithFlags(&G->ev_ready[r], hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&G->ev_done[r], hipEventDisableTiming) == hipSuccess;
-        }
-        if (!ok) { delete G; return SF_ERR_HIP; }
+        LocalGroup* G = new_local_group(nranks, devices[0]);
+        if (!G) return SF_ERR_HIP;
         for (int r = 0; r < nranks; ++r) {
             comms[r] = new sf_comm();
             comms[r]->kind = 1; comms[r]->rank = r; comms[r]->nranks = nranks; comms[r]->device = devices[0]; comms[r]->local = G;
@@ -197,6 +208,55 @@ int sf_comm_create_all(sf_comm** comms, int nranks, const int* devices) {
         comms[r]->kind = 0; comms[r]->rank = r; comms[r]->nranks = nranks; comms[r]->device = devices[r]; comms[r]->nccl = nc[r];
     }
     return SF_OK;
+}
+
+// Sub-communicators for the groups `masks` (bit r = world rank r; the same sorted list on every rank).  Collective: every
+// rank of `c` calls it with the same list -- ncclCommSplit per group for RCCL (a rank outside a group passes
+// NCCL_SPLIT_NOCOLOR), a shared LocalGroup per mask for emulated ranks.  Idempotent.
+int sf_comm_prepare_groups(sf_comm* c, const uint32_t* masks, int nmasks) {
+    if (!c || (nmasks > 0 && !masks)) return SF_ERR_ARG;
+    if (c->groups_ready) return SF_OK;
+    const uint32_t all = c->nranks >= 32 ? 0xffffffffu : ((1u << c->nranks) - 1u);
+    for (int k = 0; k < nmasks; ++k) {
+        const uint32_t m = masks[k] & all;
+        if (m == all || m == 0) continue;                       // the world itself / nobody
+        const bool mine = ((m >> c->rank) & 1u) != 0;
+        const int gsize = __builtin_popcount(m), grank = __builtin_popcount(m & ((1u << c->rank) - 1u));
+        if (c->kind == 0) {
+            ncclComm_t sub = nullptr;
+            NCCL_TRY(rccl().CommSplit(c->nccl, mine ? 0 : NCCL_SPLIT_NOCOLOR, c->rank, &sub, nullptr));
+            if (!mine) continue;
+            sf_comm* sc = new sf_comm();
+            sc->kind = 0; sc->rank = grank; sc->nranks = gsize; sc->device = c->device; sc->nccl = sub;
+            c->subs.push_back({m, sc});
+        } else {
+            if (!mine) continue;
+            LocalGroup* child = nullptr;
+            {
+                std::lock_guard<std::mutex> g(c->local->mu);
+                for (auto& kv : c->local->children)
+                    if (kv.first == m) child = kv.second;
+                if (!child) {
+                    child = new_local_group(gsize, c->device);
+                    if (child) c->local->children.push_back({m, child});
+                }
+            }
+            if (!child) return SF_ERR_HIP;
+            sf_comm* sc = new sf_comm();
+            sc->kind = 1; sc->rank = grank; sc->nranks = gsize; sc->device = c->device; sc->local = child;
+            c->subs.push_back({m, sc});
+        }
+    }
+    c->groups_ready = true;
+    return SF_OK;
+}
+
+static sf_comm* group_comm(sf_comm* c, uint32_t mask) {
+    const uint32_t all = c->nranks >= 32 ? 0xffffffffu : ((1u << c->nranks) - 1u);
+    if ((mask & all) == all) return c;
+    for (auto& kv : c->subs)
+        if (kv.first == (mask & all)) return kv.second;
+    return nullptr;
 }
 
 extern "C" {
@@ -232,6 +292,8 @@ int sf_comm_size(const sf_comm* c) { return c ? c->nranks : 0; }
 
 int sf_comm_destroy(sf_comm* c) {
     if (!c) return SF_OK;
+    for (auto& kv : c->subs) sf_comm_destroy(kv.second);
+    c->subs.clear();
     if (c->kind == 0 && c->nccl) (void)rccl().CommDestroy(c->nccl);
     if (c->kind == 1 && c->local) {
         LocalGroup* G = c->local;
@@ -244,6 +306,7 @@ int sf_comm_destroy(sf_comm* c) {
                 if (G->ev_ready[r]) (void)hipEventDestroy(G->ev_ready[r]);
                 if (G->ev_done[r]) (void)hipEventDestroy(G->ev_done[r]);
             }
+            G->children.clear();        // the sub-groups are owned (reference-counted) by their members' communicators
             delete G;
         }
     }
@@ -272,20 +335,24 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
         return sf_chol_plan_factorize(p, sync);
     }
     int rc = SF_OK;
+    // the groups of a proportionally mapped plan: their sub-communicators are made once, by all ranks together
+    if ((rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size()))) return rc;
     if (host_out && (rc = sf_dl_begin(p, host_out))) return rc;
     rc = sf_chol_plan_factorize_phase(p, 0, 0);
     const sf_long nseg = sf_chol_plan_num_segments(p);
     for (sf_long k = 0; k < nseg; ++k) {
+        sf_comm* gc = group_comm(comm, p->segments[k].mask);
+        if (!gc && !rc) rc = SF_ERR_ARG;
         if (rc) {
             // emulated ranks hand-shake on the host: a failed rank keeps taking part so that the others return too
-            if (comm->kind == 1) (void)sf_comm_allreduce_sum(comm, nullptr, -1, (void*)p->stream);
+            if (gc && gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, (void*)p->stream);
             continue;
         }
         void* buf = nullptr;
         sf_long cnt = 0;
         rc = sf_chol_plan_segment_pack(p, k, &buf, &cnt);
         if (rc) { --k; continue; }      // re-enter the loop for this segment in the failed state
-        rc = sf_comm_allreduce_sum(comm, buf, cnt, (void*)p->stream);
+        rc = sf_comm_allreduce_sum(gc, buf, cnt, (void*)p->stream);
         if (!rc) rc = sf_chol_plan_factorize_segment(p, k, 0);
     }
     int rc_dl = SF_OK;

@@ -28,7 +28,8 @@ struct Launch {
     int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
     uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
     double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
-    bool split = false;         // distributed top: every rank executes 1/nranks of this launch's units
+    bool split = false;         // distributed top: this rank executes share share_idx of share_cnt of this launch's units
+    int share_idx = 0, share_cnt = 1;
     int ticket = 0;             // k_step launches: index of the launch's task-claim counter (d_info[1 + ticket])
 };
 
@@ -37,6 +38,7 @@ struct Launch {
 // summed over the ranks; until then a block only ever received additive updates (subtree Schur updates, split top
 // Schur updates, split outer GEMMs), so its true value is the sum of the ranks' copies.
 struct Segment {
+    uint32_t mask = 0;                     // the ranks that hold (and sum) these block columns
     size_t l0 = 0, l1 = 0;                 // launches [l0, l1)
     std::vector<int64_t> off, cnt;         // whole block columns: doubles, relative to the factor base pointer
     // the part of each region that can be non-zero (rows >= the block's first column): `cols` pieces of `rows` doubles,
@@ -124,6 +126,7 @@ struct sf_chol_plan {
     size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
     int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
     std::vector<Segment> segments;
+    std::vector<uint32_t> all_masks;    // every group of the factorization (all ranks build the same sorted list)
     double* d_scratch = nullptr;   // packed segment buffer (max over the segments)
     int64_t packed_pending = -1;   // segment whose packed buffer has to be scattered back before it runs
     bool own_stream = true;

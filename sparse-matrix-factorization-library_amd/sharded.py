@@ -37,14 +37,22 @@ class _DevArray:
 
 
 class HipEngine:
-    def __init__(self, sym, phase, load_top, device, rank=0, world=1, distributed=False, group=None):
+    def __init__(self, sym, phase, load_top, device, rank=0, world=1, distributed=False, group=None, owner=None):
         self.distributed = bool(distributed and world > 1)
         self.lu = bool(getattr(sym, "lu", False))
         if self.lu and world > 1 and not self.distributed:
             raise ValueError("sharded LU needs mode='distributed'")
         cls = LUPlan if self.lu else CholPlan
+        use_c_comm = False
+        if self.distributed:
+            import torch.distributed as dist
+            use_c_comm = dist.is_initialized() and dist.get_backend(group) == "nccl" and dist.get_world_size(group) == world
         if self.lu and world == 1:
             self.plan = LUPlan(sym, device=device)
+        elif use_c_comm and owner is not None:
+            # the product path: proportionally mapped plan (a top supernode lives on the ranks below it), groups and their
+            # collectives handled by the C library
+            self.plan = cls(sym, device=device, owner=owner, rank=rank, nranks=world)
         else:
             self.plan = cls(sym, device=device, phase=phase, load_top=load_top,
                             rank=rank if self.distributed else 0, nranks=world if self.distributed else 1)
@@ -132,7 +140,7 @@ class ShardedFactorization:
         self.owner, self.top_fraction, self.max_load_fraction = subtree_partition(sym, world, self.top_weight)
         phase = phases_for_rank(self.owner, rank)
         dist_mode = self.mode == "distributed"
-        factory = engine_factory or (lambda s, ph, lt, r, w, d: HipEngine(s, ph, lt, device, r, w, d, group))
+        factory = engine_factory or (lambda s, ph, lt, r, w, d: HipEngine(s, ph, lt, device, r, w, d, group, self.owner))
         self.engine = factory(sym, phase, rank == 0, rank, world, dist_mode)
         self.phase = phase
 

@@ -111,3 +111,27 @@ def test_rccl_binding_one_rank_communicator():
     s.synchronize()
     assert torch.equal(t, want)
     comm.close()
+
+
+def test_mapped_plans_store_less_and_group_their_segments():
+    """proportional mapping (sf_chol_plan_create_mapped): a rank holds its subtrees and the top supernodes above them, not
+    the whole top; its segments name the group of ranks that sums them, the root's group is everybody"""
+    N, W = 24, 8
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 8 << 30)
+    owner, _, _ = sf.subtree_partition(sym, W, 1.0 / W + 0.25)
+    assert np.count_nonzero(owner < 0) >= 3
+    stored_mapped, stored_repl, groups = [], [], set()
+    for r in range(W):
+        pm = sf.CholPlan(sym, owner=owner, rank=r, nranks=W)
+        pr = sf.CholPlan(sym, phase=sf.phases_for_rank(owner, r), load_top=(r == 0), rank=r, nranks=W)
+        stored_mapped.append(pm.stat("stored_doubles"))
+        stored_repl.append(pr.stat("stored_doubles"))
+        gs = [pm.segment_group(k) for k in range(pm.num_segments())]
+        assert all((g >> r) & 1 for g in gs)            # a rank only meets segments of groups it belongs to
+        assert gs[-1] == (1 << W) - 1                   # the root is shared by everybody
+        groups.update(gs)
+        pm.close()
+        pr.close()
+    assert len(groups) >= 3                             # nested groups: pairs, quads, all
+    assert max(stored_mapped) < 0.9 * max(stored_repl)
