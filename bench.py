@@ -263,8 +263,10 @@ def main():
                                f"3D 7-point Laplacian {N}^3 SPD Cholesky fp64, geometric ND, devSlotSize {sf.REFERENCE_SLOT_1GPU}",
                    "n": n, "nnz_input": int(nnz_in), "nsuper": int(sym.nsuper), "factor_doubles": int(sym.xsize),
                    "F_struct": F_struct, "F_exec": F_exec,
-                   "parallelism": (("elimination-tree subtrees sharded over the GPUs; top supernodes: large GEMMs split over the "
-                                    "ranks, every top panel all-reduced once (RCCL) block by block, 64-column chains replicated")
+                   "parallelism": (("elimination-tree subtrees sharded over the GPUs; top supernodes proportionally mapped (a top "
+                                    "supernode lives on the ranks whose subtrees lie below it): large GEMMs split over that group, every "
+                                    "top panel all-reduced once inside it (RCCL sub-communicators, issued by the C library on the "
+                                    "plan's stream) block by block, 64-column chains replicated inside the group")
                                    if sharded.mode == "distributed" else
                                    ("elimination-tree subtrees sharded over the GPUs, one RCCL all-reduce of the top panels, "
                                     "top supernodes replicated")) if sharded is not None else

@@ -205,6 +205,8 @@ int sf_comm_rank(const sf_comm *comm);
 int sf_comm_size(const sf_comm *comm);
 int sf_comm_allreduce_sum(sf_comm *comm, void *device_buf, sf_long count, void *hip_stream);
 int sf_comm_destroy(sf_comm *comm);
+/* test hook: split the communicator (all ranks, one colour), all-reduce on the child, destroy it */
+int sf_comm_selftest_split(sf_comm *comm, void *device_buf, sf_long count, void *hip_stream);
 int sf_chol_plan_factorize_distributed(sf_chol_plan *plan, sf_comm *comm, sf_float *host_out /* or NULL */, int sync);
 
 /* ---- device plan for supernodal no-pivot LU (replaces L:2668-3573 + LU/Source/cuda_kernel.cu:22-176).

@@ -130,6 +130,8 @@ lib.sf_comm_create_rccl.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c
 lib.sf_comm_create_rccl.restype = C.c_int
 lib.sf_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
 lib.sf_comm_allreduce_sum.restype = C.c_int
+lib.sf_comm_selftest_split.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+lib.sf_comm_selftest_split.restype = C.c_int
 lib.sf_comm_destroy.argtypes = [C.c_void_p]
 lib.sf_comm_destroy.restype = C.c_int
 lib.sf_comm_rank.argtypes = [C.c_void_p]

@@ -167,6 +167,22 @@ def subtree_partition(sym, nranks, top_weight=1.0):
     return owner[:sym.nsuper], tf.value, ml.value
 
 
+def top_groups(sym, owner):
+    """mask[s] for the top supernodes (owner[s] < 0): bit r set = rank r owns a subtree below s -- the group of ranks that
+    holds s under the proportional mapping (what sf_chol_plan_create_mapped derives internally); 0 for subtree supernodes"""
+    ns = sym.nsuper
+    mask = np.zeros(ns, dtype=np.uint32)
+    own = np.asarray(owner)
+    mask[own >= 0] = np.left_shift(np.uint32(1), own[own >= 0].astype(np.uint32))
+    Super, Lsip, Lsi, SuperMap = sym.Super, sym.Lsip, sym.Lsi, sym.SuperMap
+    for s in range(ns):
+        nscol, nsrow = Super[s + 1] - Super[s], Lsip[s + 1] - Lsip[s]
+        if nscol < nsrow:
+            mask[SuperMap[Lsi[Lsip[s] + nscol]]] |= mask[s]
+    mask[own >= 0] = 0
+    return mask
+
+
 def phases_for_rank(owner, rank):
     """phase array of sf_chol_plan_create_sharded for `rank`: 0 own subtree, 1 top (replicated), -1 elsewhere"""
     return np.where(owner == rank, 0, np.where(owner < 0, 1, -1)).astype(np.int32)

@@ -287,6 +287,19 @@ int sf_comm_create_rccl(sf_comm** out, int device, int rank, int nranks, const c
     return SF_OK;
 }
 
+// test hook: ncclCommSplit of the whole communicator (every rank passes color 0), one all-reduce on the child, destroy --
+// the sub-communicator calls of the proportional mapping on the real library even where only one rank exists
+int sf_comm_selftest_split(sf_comm* c, void* device_buf, sf_long count, void* stream) {
+    if (!c || c->kind != 0 || !rccl().ok) return SF_ERR_ARG;
+    ncclComm_t sub = nullptr;
+    NCCL_TRY(rccl().CommSplit(c->nccl, 0, c->rank, &sub, nullptr));
+    if (!sub) return SF_ERR_HIP;
+    const ncclResult_t r = rccl().AllReduce(device_buf, device_buf, (size_t)count, ncclDouble, ncclSum, sub, (hipStream_t)stream);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)rccl().CommDestroy(sub);
+    return (r == ncclSuccess && e == hipSuccess) ? SF_OK : SF_ERR_HIP;
+}
+
 int sf_comm_rank(const sf_comm* c) { return c ? c->rank : -1; }
 int sf_comm_size(const sf_comm* c) { return c ? c->nranks : 0; }
 

@@ -21,7 +21,7 @@ methods (tests use a numpy engine so that the orchestration runs under gloo with
 """
 import numpy as np
 
-from .api import CholPlan, LUPlan, subtree_partition, phases_for_rank
+from .api import CholPlan, LUPlan, subtree_partition, phases_for_rank, top_groups
 
 #: cost of a top flop relative to a subtree flop in the distributed mode: the split share plus the replicated
 #: 64-column chain and the all-reduce (about a quarter of the top's single-GPU time at 128^3)
@@ -197,14 +197,18 @@ class ShardedFactorization:
         sub = np.zeros_like(mine)
         for s in np.flatnonzero(self.phase == 0):
             sub[S.Lsxp[s]:S.Lsxp[s + 1]] = mine[S.Lsxp[s]:S.Lsxp[s + 1]]
+        # a top panel is identical on the ranks of its group: the group's first rank contributes it (a rank outside the
+        # group does not hold it under the proportional mapping)
+        masks = top_groups(S, self.owner)
+        for s in np.flatnonzero(self.owner < 0):
+            m = int(masks[s])
+            if m and (m & -m) == (1 << self.rank):
+                sub[S.Lsxp[s]:S.Lsxp[s + 1]] = mine[S.Lsxp[s]:S.Lsxp[s + 1]]
         t = torch.from_numpy(sub)
         if dist.get_backend(self.group) == "nccl":
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        full = t.cpu().numpy()
-        for s in np.flatnonzero(self.phase == 1):
-            full[S.Lsxp[s]:S.Lsxp[s + 1]] = mine[S.Lsxp[s]:S.Lsxp[s + 1]]
-        return full
+        return t.cpu().numpy()
 
     def close(self):
         self.engine.close()

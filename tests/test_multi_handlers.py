@@ -110,6 +110,11 @@ def test_rccl_binding_one_rank_communicator():
     comm.allreduce_sum(t.data_ptr(), t.numel(), s.cuda_stream)
     s.synchronize()
     assert torch.equal(t, want)
+    # the sub-communicator calls of the proportional mapping (ncclCommSplit + a collective on the child)
+    from util import sf as _sf
+    lib = __import__("importlib").import_module("sparse-matrix-factorization-library_amd._lib").lib
+    assert lib.sf_comm_selftest_split(comm._h, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(s.cuda_stream)) == 0
+    assert torch.equal(t, want)
     comm.close()
 
 

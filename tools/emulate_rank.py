@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--replicated-top", action="store_true",
+                    help="round-1 layout: every rank stores every top panel (default: proportional mapping, a top supernode lives on "
+                         "the ranks whose subtrees lie below it)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -35,6 +38,10 @@ def main():
     sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g, 3, 1), sf.REFERENCE_SLOT_1GPU)
     owner, tf, ml = sf.subtree_partition(sym, W, 1.0 / W + sharded.TOP_CHAIN_SHARE)
     eng = sharded.HipEngine(sym, sf.phases_for_rank(owner, args.rank), args.rank == 0, 0, args.rank, W, True)
+    if not args.replicated_top:
+        eng.plan.close()
+        eng.plan = sf.CholPlan(sym, device=0, owner=owner, rank=args.rank, nranks=W)
+        eng.plan.set_stream(torch.cuda.current_stream(0).cuda_stream)
     eng.set_values(sym.Lx)
     nseg = eng.num_segments()
     full_doubles = sum(c for k in range(nseg) for (_, c) in eng.plan.segment_regions(k))
@@ -61,7 +68,9 @@ def main():
                       "phase0_ms": round(p0, 2), "segments_ms": round(p1, 2), "segments": nseg,
                       "allreduce_calls": nseg, "allreduce_bytes": 8 * res[0][2], "top_panel_bytes": 8 * full_doubles,
                       "top_flop_fraction": tf, "max_rank_subtree_flop_fraction": ml,
-                      "stored_doubles": eng.plan.stat("stored_doubles")}))
+                      "stored_doubles": eng.plan.stat("stored_doubles"),
+                      "layout": "replicated top" if args.replicated_top else "proportional mapping",
+                      "segment_groups": sorted({bin(eng.plan.segment_group(k)).count("1") for k in range(nseg)})}))
     eng.close()
 
 
