@@ -23,6 +23,7 @@
 //
 // Wavefronts are 64 wide; all tilings below are written for that.
 #include "sf_kernels.h"
+#include <cstdlib>
 #include "sf_wave.h"
 
 namespace sf {
@@ -556,7 +557,13 @@ __device__ __forceinline__ int last_le_u32(const uint32_t* __restrict__ a, int n
 // contiguous, equal share of the remaining units, so the chip stays full whatever the mix of tile counts and K
 // lengths (no tail of half-empty rounds).  Every tile is combined into its target with fp64 atomics (a K range
 // split between workgroups needs them anyway).
-template <int MODE>
+// DMA: the operand tiles go global -> LDS directly (global_load_lds_dwordx4, "LDS-DMA"): the [k][row] LDS image of one k is
+// 128 doubles = 1 KiB = exactly what one wave instruction writes (lane l: rows 2l, 2l+1), and it is 1 KiB of one panel column in
+// memory too.  No staging registers, no ds_write, no select instructions; a k beyond K reads the X operand from a page of
+// zeros (a DMA cannot mask), rows beyond M / N read valid memory whose products only reach entries that are never stored.
+__device__ double g_zero_page[GEMM_BM + 16];
+
+template <int MODE, bool DMA>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
@@ -657,9 +664,10 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         const bool x0_ok = (cj0 + prow) < N, x1_ok = (cj0 + prow + 1) < N;
         const double* __restrict__ yp = Yg + (y0_ok ? prow : 0);
         const double* __restrict__ xp = Xg + (x0_ok ? prow : 0);
-        double2_t ry[SQ], rx[SQ];
+        double2_t ry[DMA ? 1 : SQ], rx[DMA ? 1 : SQ];
 
         auto load_tile = [&](int k0) {
+            if (DMA) return;
 #pragma unroll
             for (int q = 0; q < SQ; ++q) {
                 const int64_t off = (int64_t)min(k0 + pk0 + GEMM_WAVES * q, K - 1) * lda;
@@ -668,6 +676,19 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
             }
         };
         auto store_tile = [&](int buf, int k0) {
+            if (DMA) {
+                // wave `pk0` fills k rows pk0 and pk0 + 8 of both operands: four 1 KiB DMAs per K step and wave
+#pragma unroll
+                for (int q = 0; q < SQ; ++q) {
+                    const int kl = pk0 + GEMM_WAVES * q, k = k0 + kl;
+                    const bool kin = k < K;                                     // wave-uniform
+                    const double* ysrc = yp + (int64_t)min(k, K - 1) * lda;
+                    const double* xsrc = kin ? xp + (int64_t)k * lda : g_zero_page + prow;
+                    __builtin_amdgcn_global_load_lds((const void*)ysrc, (__attribute__((address_space(3))) void*)&Ys[buf][kl][0], 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const void*)xsrc, (__attribute__((address_space(3))) void*)&Xs[buf][kl][0], 16, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < SQ; ++q) {
                 const bool kin = (k0 + pk0 + GEMM_WAVES * q) < K;
@@ -1311,10 +1332,18 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
     if (ntasks <= 0 || u_hi <= u_lo) return;
     const uint32_t units = u_hi - u_lo;
     const uint32_t grid = units < (uint32_t)GEMM_GRID ? units : (uint32_t)GEMM_GRID;
+    static const bool dma = [] { const char* e = getenv("SF_GEMM_DMA"); return e ? atoi(e) != 0 : false; }();
+    if (dma) {
+        if (mode == 1)
+            hipLaunchKernelGGL((k_gemm<1, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+        else
+            hipLaunchKernelGGL((k_gemm<0, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+        return;
+    }
     if (mode == 1)
-        hipLaunchKernelGGL(k_gemm<1>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+        hipLaunchKernelGGL((k_gemm<1, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
     else
-        hipLaunchKernelGGL(k_gemm<0>, dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+        hipLaunchKernelGGL((k_gemm<0, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
 }
 
 }  // namespace sf
