@@ -452,3 +452,17 @@ def test_struct_entry_point_reuses_cached_plan(oracle):
     mi.cleanup()
     common.close()
     assert times[1] < times[0] and times[2] < times[0]          # the plan was built once
+
+
+def test_gemm_register_staged_form(oracle, monkeypatch):
+    """k_gemm stages its operand tiles by LDS-DMA (global_load_lds_dwordx4) by default; SF_GEMM_DMA=0 selects the
+    register-staged form.  Both must give the oracle's factor (wide supernodes: K tails, odd panel offsets, edge tiles)."""
+    n, Cp, Ci, Cx = gen.laplacian_lower(18, 17, 19)
+    sym = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(18, 17, 19), 8 << 30)
+    ref, info, _ = oracle.chol_factorize(sym)
+    mask = oracle.lower_mask(sym)
+    for dma in ("1", "0"):
+        monkeypatch.setenv("SF_GEMM_DMA", dma)
+        plan, Lsx = gpu_factor(sym)
+        plan.close()
+        assert rel_err(Lsx, ref, mask) <= TOL_FACTOR, dma
