@@ -535,23 +535,44 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     p->n_gemm_tasks = (int64_t)gtasks.size() + (int64_t)stasks.size();
 
     // ---------------- device solve schedule (unsharded plans) ----------------
-    // per (level, 64-column step): a forward launch [diagonal tasks, 256-row tiles] and a backward launch [tiles, diagonal tasks]
+    // per (level, SV_B-column step): a forward launch [diagonal tasks, SV_ROWS-row tiles] and a backward launch [tiles, diagonal tasks]
     std::vector<sf::SolveTask> solve;
     int32_t n_solve_sync = 0;
     if (!p->partial) {
         std::vector<std::vector<sf_long>> by_level(nlevels);
         for (sf_long s = 0; s < nsuper; ++s) by_level[level[s]].push_back(s);
-        const int tile = 256;
+        const int tile = sf::SV_ROWS;
+        // default: fused (35.3 ms at 128^3); SF_SOLVE_BWD_FUSED=0: two launches per backward step (38.2 ms)
+        const bool bwd_fused = !(getenv("SF_SOLVE_BWD_FUSED") && atoi(getenv("SF_SOLVE_BWD_FUSED")) == 0);
+        p->solve_bwd_fused = bwd_fused;
         for (int l = 0; l < nlevels; ++l) {
             sf_long maxcol = 0;
             for (sf_long s : by_level[l]) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
-            for (int diag = 0; diag < maxcol; diag += sf::NB) {
+            // the narrow panels of the level (nscol <= 64; the swarm levels consist of nothing else) go to the
+            // one-wave-per-supernode kernels as a step of their own, the wide ones through the general 256-column steps
+            std::vector<sf_long> narrow, wide;
+            for (sf_long s : by_level[l]) ((Super[s + 1] - Super[s] <= sf::NB) ? narrow : wide).push_back(s);
+            if (narrow.size() < 64) { wide = by_level[l]; narrow.clear(); }     // not worth a launch of their own
+            if (!narrow.empty()) {
+                sf_chol_plan::SolveStep st{};
+                st.small = 1;
+                st.fwd_first = st.bwd_first = (int64_t)solve.size();
+                for (sf_long s : narrow) {
+                    const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                    solve.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, 0, nscol, 0, 0, (int32_t)Super[s], 0, 0});
+                }
+                st.count = st.ndiag = (int)narrow.size();
+                p->solve_steps.push_back(st);
+            }
+            maxcol = 0;
+            for (sf_long s : wide) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
+            for (int diag = 0; diag < maxcol; diag += sf::SV_B) {
                 sf_chol_plan::SolveStep st{};
                 std::vector<sf::SolveTask> dg, rows;
-                for (sf_long s : by_level[l]) {
+                for (sf_long s : wide) {
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
                     if (diag >= nscol) continue;
-                    const int b = std::min(sf::NB, nscol - diag);
+                    const int b = std::min(sf::SV_B, nscol - diag);
                     const int ntiles = (nsrow - diag - b + tile - 1) / tile;
                     // sync words: [flag] forward "solved" flag, [flag + 1] backward tile counter
                     dg.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, b, 0, 0, (int32_t)Super[s], n_solve_sync, ntiles});
@@ -564,8 +585,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 solve.insert(solve.end(), rows.begin(), rows.end());
                 st.bwd_first = (int64_t)solve.size();
                 for (sf::SolveTask t : rows) { t.flag += 1; solve.push_back(t); }
-                for (sf::SolveTask t : dg) { t.flag += 1; solve.push_back(t); }
+                // backward: one launch, the diagonal task waits for a tile counter (SF_SOLVE_BWD_FUSED=0: the row tiles and
+                // the diagonal tasks as TWO launches -- measured slower)
+                for (sf::SolveTask t : dg) { t.flag += 1; if (!bwd_fused) t.expect = 0; solve.push_back(t); }
                 st.count = (int)(dg.size() + rows.size());
+                st.nrows_tasks = (int)rows.size();
+                st.big = 0;
+                for (const sf::SolveTask& t : dg) st.big |= t.b > sf::NB;
+                st.small = 0;
+                st.ndiag = (int)dg.size();
                 p->solve_steps.push_back(st);
             }
         }
@@ -716,7 +744,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (!solve.empty()) {
             if ((rc = upload(&p->d_solve, solve, &p->bytes_device))) break;
             // sync words of the solve: [0] status, then the flags / counters, then two launch tickets per step
-            const size_t sb = (size_t)(1 + p->n_solve_sync + 2 * p->solve_steps.size()) * sizeof(int);
+            const size_t sb = (size_t)(1 + p->n_solve_sync + 3 * p->solve_steps.size()) * sizeof(int);
             if (hipMalloc((void**)&p->d_solve_sync, sb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += sb;
             if (hipMalloc((void**)&p->d_x, std::max<int64_t>(n, 1) * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
@@ -1408,16 +1436,31 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     const size_t nst = p->solve_steps.size();
     int* sync = p->d_solve_sync + 1;
     int* tickets = sync + p->n_solve_sync;
-    HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + 2 * nst) * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + 3 * nst) * sizeof(int), st));
     for (size_t k = 0; k < nst; ++k) {
         const auto& s = p->solve_steps[k];
-        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.count, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
-                             (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, sync, tickets + 2 * k,
+        if (s.small) {
+            sf::launch_solve_small_fwd(p->d_solve + s.fwd_first, s.ndiag, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
+                                       (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, st);
+            continue;
+        }
+        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.count, s.big, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
+                             (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, sync, tickets + 3 * k,
                              p->d_solve_sync, st);
     }
     for (size_t k = nst; k-- > 0;) {
         const auto& s = p->solve_steps[k];
-        sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 2 * k + 1, p->d_solve_sync, st);
+        if (s.small) {
+            sf::launch_solve_small_bwd(p->d_solve + s.bwd_first, s.ndiag, bwd_base, p->d_Lsi, p->d_x, st);
+            continue;
+        }
+        if (p->solve_bwd_fused) {
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
+        } else {
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.nrows_tasks, 0, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first + s.nrows_tasks, s.count - s.nrows_tasks, s.big, bwd_base, p->d_Lsi, p->d_x, sync,
+                                 tickets + 3 * k + 2, p->d_solve_sync, st);
+        }
     }
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipGetLastError());

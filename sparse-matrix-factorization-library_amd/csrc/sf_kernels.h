@@ -17,6 +17,8 @@ constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
 constexpr int GEMM_GRID = 512;   // persistent GEMM grid: 2 workgroups per CU x 256 CUs
 constexpr int GEMM_SLICE = 1 << 30;  // K steps per task (a tile's K range could be cut into slices; measured: it does not pay)
 constexpr int SU_TM = 64, SU_TN = 32;   // tile of k_update_small (one wave): rows x columns
+constexpr int SV_B = 256;         // columns per step of the device solve (4 sub-blocks of NB, one per wave)
+constexpr int SV_ROWS = 64;       // rows per row tile of the device solve
 constexpr int SU_MAXK = 64;      // Schur updates with K <= SU_MAXK go to k_update_small
 
 // One C -= Y * X^T problem on rows of ONE source panel (column-major, leading dimension lda):
@@ -133,13 +135,13 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
 void launch_update_small(const GemmProb* probs, const GemmTask* tasks, int ntasks, double* Lsx, const int32_t* RelMap, hipStream_t st);
 
 // ---- device-side supernodal triangular solves with the resident factor (reference: scalar host loops,
-// Cholesky/Source/SparseFrame.c:3074-3134).  64-column block steps, the same (level, step) sweep as the factorization;
-// one launch per step and direction, the diagonal solve and the row tiles hand over inside the launch.
+// Cholesky/Source/SparseFrame.c:3074-3134).  SV_B-column steps level by level; one launch per step and direction, the
+// diagonal solve (one workgroup, wave w = 64-column sub-block w) and the SV_ROWS-row tiles hand over inside the launch.
 struct SolveTask {
     int64_t panel;      // doubles, into Lsx
     int64_t rows;       // index into Lsi of the supernode's row list
-    int32_t ld, diag, b;
-    int32_t row0, nrows;    // row tile: rows [row0, row0 + nrows) of the panel (below the block); nrows == 0: the diagonal task
+    int32_t ld, diag, b;    // the step's columns [diag, diag + b), b <= SV_B
+    int32_t row0, nrows;    // row tile: rows [row0, row0 + nrows) of the panel (below the block), nrows <= SV_ROWS; nrows == 0: the diagonal task
     int32_t first_col;      // Super[s]
     int32_t flag;           // index into the solve's sync words: forward = "x_blk is solved" flag, backward = tile counter
     int32_t expect;         // backward diagonal task: number of row tiles to wait for
@@ -147,9 +149,15 @@ struct SolveTask {
 // forward launch: tasks = the step's diagonal tasks, then its row tiles; backward launch: the row tiles, then the diagonal
 // tasks.  sync: one word per (panel, step) and direction, zero at the start of the solve; ticket: zero, private to the launch
 // pivpos != nullptr (LU with pivoting): x_blk is brought into the block's pivot order before the unit-lower solve
-void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
+// steps whose panels are all narrow (nscol <= 64): one wave per supernode does its diagonal solve and all its rows, no
+// hand-off; tasks = the step's diagonal tasks only (task.ld = nsrow, task.b = nscol)
+void launch_solve_small_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
+                            hipStream_t st);
+void launch_solve_small_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st);
+// big != 0: some panel of the step has more than one 64-column sub-block (the variant with the prefetch registers)
+void launch_solve_fwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
                       int* sync, int* ticket, int* info, hipStream_t st);
-void launch_solve_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
+void launch_solve_bwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
                       hipStream_t st);
 
 }  // namespace sf

@@ -343,16 +343,17 @@ void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, const int32_t* 
 
 // ---------------------------------------------------------------------------------------------------
 // Triangular solves with the resident factor (L L^T x = b or L U x = b, permuted space; reference: scalar host loops,
-// C:3074-3134, L:3592-3700), one launch per (level, 64-column step) and sweep direction:
-//   forward : x_blk <- D^{-1} x_blk (one wave, row r of D in lane r's registers)  ;  x[rows below] -= L[rows, blk] x_blk
-//   backward: x_blk -= L[rows below, blk]^T x[rows below]                         ;  x_blk <- D^{-T} x_blk
-// The two halves of a step run in ONE launch and hand over inside it, like k_step: tasks are claimed by ticket in
-// execution order (the producers come first in the list, so they are always running before a consumer can wait).
-//   forward : the 256-row tiles load their 64 columns into registers WHILE the diagonal wave solves, then wait for
-//             its flag, read x_blk and subtract their dot products (fp64 atomics: supernodes of one level share ancestors)
-//   backward: the tiles reduce their columns and add the partial sums to x_blk atomically, then count themselves in;
-//             the diagonal wave loads D meanwhile and solves once the count is complete
-// The substitution has no division on its 64-step chain: lane j forms 1 / D(j,j) up front.
+// C:3074-3134, L:3592-3700).  The sweep is a chain of dependent steps, so the step is made BIG and its inside cheap:
+// one launch per (level, 256-column step) and direction (SV_B = 256),
+//   forward : x_blk <- D^{-1} x_blk  (256 x 256 lower-triangular block)  ;  x[rows below] -= L[rows, blk] x_blk
+//   backward: x_blk -= L[rows below, blk]^T x[rows below]               ;  x_blk <- D^{-T} x_blk
+// and both halves hand over INSIDE the launch (tasks claimed by ticket in execution order, producers first in the list).
+// Diagonal task = one workgroup, wave w owns the 64-column sub-block w: its 64 x 64 triangle sits in the lane's registers
+// from the start (all four waves load at once), the off-diagonal 64 x 64 blocks are prefetched one sub-step ahead, the
+// solved sub-vector goes round through LDS: 4 substitution chains of 64 and 3 barriers instead of 4 launches with 4
+// device-scope hand-offs.  No division on the chains (lane j forms 1 / D(j,j) up front).
+// Row tiles = 64 rows x the step's columns: thread (lane, wave) = (row, 64-column chunk) forward, (column, chunk)
+// backward, ALL its 64 matrix entries are in flight before the hand-off, after it 64 FMAs and one atomic.
 // ---------------------------------------------------------------------------------------------------
 constexpr int SV_SPIN_LIMIT = 1 << 22;
 
@@ -366,110 +367,150 @@ __device__ __forceinline__ void sv_publish(int* flag, int value) {
 __device__ __forceinline__ void sv_wait(const int* flag, int value, int* info) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(16);       // hundreds of waiting workgroups poll ONE address: keep the L2 channel usable for its writer
         if (++spins > SV_SPIN_LIMIT) { atomicOr(info, 2); break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ void __launch_bounds__(256)
+template <bool BIG>
+__global__ void __launch_bounds__(256, BIG ? 1 : 2)
 k_solve_fwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
             double* __restrict__ x, int unit, const int32_t* __restrict__ pivpos, int* __restrict__ sync, int* __restrict__ ticket,
             int* __restrict__ info) {
     __shared__ int s_ticket;
-    __shared__ double xb[NB];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ double xs[SV_B];
+    __shared__ double part[4][NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const SolveTask t = tasks[__builtin_amdgcn_readfirstlane(s_ticket)];
-    const int b = t.b;
+    const int b = t.b;                  // <= SV_B columns in this step
     const int64_t ld = t.ld;
-    if (t.nrows == 0) {                 // diagonal task: wave 0 solves, the others leave
-        if (tid >= 64) return;
-        const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * ld;
-        double a[NB];       // unit: the diagonal is implied (LU: the L panel stores only the strictly lower part)
+    const int o = NB * wave;
+    const int bw = min(NB, max(0, b - o));      // this wave's part of the step's columns
+    if (t.nrows == 0) {                 // ---- diagonal task ----
+        const double* P = Lsx + t.panel;
+        double a[NB];       // row `lane` of the sub-block's triangle; unit: the diagonal is implied (LU: the L panel)
+        if (bw > 0) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            // unconditional load from a clamped address, then select: a load under a per-element condition becomes a branch
-            // plus its own s_waitcnt, i.e. 64 dependent round trips
-            const double v = D[min(lane, b - 1) + (int64_t)min(c, b - 1) * ld];
-            a[c] = (lane < b && c + unit <= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+            for (int c = 0; c < NB; ++c) {
+                // unconditional loads from clamped addresses, then select (a load under a per-element condition becomes a
+                // branch plus its own s_waitcnt: 64 dependent round trips)
+                const double v = P[(t.diag + o + min(lane, bw - 1)) + (int64_t)(t.diag + o + min(c, bw - 1)) * ld];
+                a[c] = (lane < bw && c + unit <= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) a[c] = (c == lane) ? 1.0 : 0.0;
         }
-        double* xq = x + t.first_col + t.diag;
-        double v = (lane < b) ? xq[lane] : 0.0;
-        if (pivpos) {
-            // LU with pivoting: the block's row interchanges, applied here (LINPACK-style: the L entries to the left of a
-            // block were stored at their rows' original places, so x is permuted block by block as the sweep reaches it)
-            const int g0 = t.first_col + t.diag;
-            if (lane < b) xb[pivpos[g0 + lane] - g0] = v;
-            v = (lane < b) ? xb[lane] : 0.0;     // one wave: LDS operations complete in order
-        }
+        double* xq = x + t.first_col + t.diag + o;
+        double v = (lane < bw) ? xq[lane] : 0.0;
         double dinv = 1.0;
 #pragma unroll
         for (int c = 0; c < NB; ++c) dinv = (c == lane) ? 1.0 / a[c] : dinv;
+        const int nsub = (b + NB - 1) / NB;
+        for (int tt = 0; tt < nsub; ++tt) {
+            const bool below = BIG && wave > tt && bw > 0;
+            double blk[BIG ? NB : 1];       // L(this wave's row, columns of sub-block tt): in flight while wave tt solves
+            if (BIG && below) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
-            if (lane == j) v = xj;
-            if (lane > j) v -= a[j] * xj;
+                for (int k = 0; k < NB; ++k) blk[k] = P[(t.diag + o + min(lane, bw - 1)) + (int64_t)(t.diag + NB * tt + k) * ld];
+            }
+            if (wave == tt) {
+                if (pivpos) {
+                    // LU with pivoting: the row interchanges of this 64-column block, applied as the sweep reaches it
+                    // (LINPACK-style: the L entries to the left of a block were stored at their rows' original places)
+                    const int g0 = t.first_col + t.diag + o;
+                    if (lane < bw) part[0][pivpos[g0 + lane] - g0] = v;
+                    v = (lane < bw) ? part[0][lane] : 0.0;       // one wave: LDS operations complete in order
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
+                    if (lane == j) v = xj;
+                    if (lane > j) v -= a[j] * xj;
+                }
+                xs[o + lane] = (lane < bw) ? v : 0.0;
+            }
+            if (BIG) {
+                __syncthreads();
+                if (below) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) v -= blk[k] * xs[NB * tt + k];
+                }
+            }
         }
-        if (lane < b) xq[lane] = v;
-        if (lane == 0) sv_publish(sync + t.flag, 1); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < bw) xq[lane] = v;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) sv_publish(sync + t.flag, 1);
         return;
     }
-    // row tile: this thread's row of the 64 columns, in flight while the diagonal block is solved
-    const int r = t.row0 + min(tid, t.nrows - 1);
-    const double* Lr = Lsx + t.panel + r + (int64_t)t.diag * ld;
+    // ---- row tile: lane = row, wave = 64-column chunk; the 64 entries are in flight while the diagonal block is solved ----
+    const int r = t.row0 + min(lane, t.nrows - 1);
+    const double* Lr = Lsx + t.panel + r + (int64_t)(t.diag + o) * ld;
     double lr[NB];
+    if (bw > 0) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) lr[k] = Lr[(int64_t)min(k, b - 1) * ld];
+        for (int k = 0; k < NB; ++k) lr[k] = Lr[(int64_t)min(k, bw - 1) * ld];
+    }
     const int32_t gi = Lsi[t.rows + r];
     if (tid == 0) sv_wait(sync + t.flag, 1, info);
     __syncthreads();
-    if (tid < NB) xb[tid] = (tid < b) ? __builtin_nontemporal_load(x + t.first_col + t.diag + tid) : 0.0;
+    xs[tid] = (tid < b) ? __builtin_nontemporal_load(x + t.first_col + t.diag + tid) : 0.0;
     __syncthreads();
     double acc = 0.0;
+    if (bw > 0) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) acc += lr[k] * xb[k];       // columns beyond b meet xb = 0
-    if (tid < t.nrows) unsafeAtomicAdd(x + gi, -acc);
+        for (int k = 0; k < NB; ++k) acc += lr[k] * xs[o + k];       // columns beyond b meet xs = 0
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < t.nrows) unsafeAtomicAdd(x + gi, -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]));
 }
 
-// row tiles: wave w sums columns 16 w .. 16 w + 15 of the block over the tile's rows, four columns at a time (independent
-// loads in flight), one atomic per column, then the tile counts itself in; diagonal task: waits for `expect` tiles
-__global__ void __launch_bounds__(256)
+template <bool BIG>
+__global__ void __launch_bounds__(256, BIG ? 1 : 2)
 k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
             double* __restrict__ x, int* __restrict__ sync, int* __restrict__ ticket, int* __restrict__ info) {
     __shared__ int s_ticket;
-    __shared__ double xr[256];
-    __shared__ double Dl[NB][NB + 1];
+    __shared__ double xs[SV_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const SolveTask t = tasks[__builtin_amdgcn_readfirstlane(s_ticket)];
     const int b = t.b;
+    const int64_t ld = t.ld;
+    const int o = NB * wave;
+    const int bw = min(NB, max(0, b - o));
     if (t.nrows > 0) {
-        xr[tid] = (tid < t.nrows) ? x[Lsi[t.rows + t.row0 + tid]] : 0.0;
-        __syncthreads();
-        const double* Lt = Lsx + t.panel + t.row0 + (int64_t)t.diag * t.ld;
-        for (int c0 = wave * 16; c0 < min(wave * 16 + 16, b); c0 += 4) {
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        // ---- row tile: lane = row (coalesced loads), wave = 64-column chunk.  p[k] = L(row, column k) x_row has to be summed
+        // over the 64 lanes for every k: a transposing butterfly -- in the step with mask m a lane keeps the half of its
+        // array that matches its bit m and adds the partner's other half -- leaves lane l with the sum of ONE column after
+        // 63 exchanges instead of 64 full reductions.
+        const int rr = t.row0 + min(lane, t.nrows - 1);
+        const double* Lr = Lsx + t.panel + rr + (int64_t)(t.diag + o) * ld;
+        double p[NB];
+        if (bw > 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double* col = Lt + (int64_t)min(c0 + u, b - 1) * t.ld;
+            for (int k = 0; k < NB; ++k) p[k] = Lr[(int64_t)min(k, bw - 1) * ld];
+            const double xr = (lane < t.nrows) ? x[Lsi[t.rows + rr]] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = lane + 64 * q;
-                    acc[u] += col[min(i, t.nrows - 1)] * xr[i];         // rows beyond the tile meet xr = 0
+            for (int k = 0; k < NB; ++k) p[k] *= xr;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const bool up = (lane & m) != 0;
+#pragma unroll
+                for (int i = 0; i < m; ++i) {
+                    const double keep = up ? p[i + m] : p[i];
+                    const double give = up ? p[i] : p[i + m];
+                    p[i] = keep + __shfl_xor(give, m, 64);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double v = acc[u];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if (lane == 0 && c0 + u < b) unsafeAtomicAdd(x + t.first_col + t.diag + c0 + u, -v);
-            }
+            // lane l now holds the column whose index has bit m set exactly where l has it: column l
+            if (lane < bw) unsafeAtomicAdd(x + t.first_col + t.diag + o + lane, -p[0]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -479,50 +520,191 @@ k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
         }
         return;
     }
-    if (tid >= 64) return;
-    const double* D = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
-    {   // Dl[c][r] = D(r,c), coalesced along r; all 64 loads in flight (clamped addresses), then the LDS stores
-        double col[NB];
+    // ---- diagonal task: x_blk <- D^{-T} x_blk, sub-blocks from the last to the first; lane = column ----
+    const double* P = Lsx + t.panel;
+    double bcol[NB];    // bcol[c] = D(c, lane): column `lane` of the sub-block's triangle, rows c >= lane (one contiguous run per
+                        // lane: 64 cache lines per load instruction, ~7 us per block -- measured cheaper than coalesced row loads
+                        // plus an in-wave transpose through LDS, which made the backward sweep 23 -> 36 ms)
+    if (bw > 0) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) col[c] = D[min(lane, b - 1) + (int64_t)min(c, b - 1) * t.ld];
+        for (int c = 0; c < NB; ++c) {
+            const double v = P[(t.diag + o + min(c, bw - 1)) + (int64_t)(t.diag + o + min(lane, bw - 1)) * ld];
+            bcol[c] = (lane < bw && c < bw && c >= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+        }
+    } else {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) Dl[c][lane] = (lane < b && c < b && lane >= c) ? col[c] : 0.0;
+        for (int c = 0; c < NB; ++c) bcol[c] = (c == lane) ? 1.0 : 0.0;
     }
-    double bcol[NB];    // bcol[c] = D(c, lane): column `lane` of D, rows c >= lane (one wave: no barrier needed, LDS ops are in order)
-#pragma unroll
-    for (int c = 0; c < NB; ++c) bcol[c] = (lane < b && c < b && c >= lane) ? Dl[lane][c] : ((c == lane) ? 1.0 : 0.0);
     double dinv = 1.0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) dinv = (c == lane) ? 1.0 / bcol[c] : dinv;
     if (t.expect > 0) {
-        if (lane == 0) {
+        if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(sync + t.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t.expect) {
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > SV_SPIN_LIMIT) { atomicOr(info, 2); break; }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
-    double* xq = x + t.first_col + t.diag;
-    double v = (lane < b) ? __builtin_nontemporal_load(xq + min(lane, b - 1)) : 0.0;
+    double* xq = x + t.first_col + t.diag + o;
+    double v = (lane < bw) ? __builtin_nontemporal_load(xq + min(lane, max(bw, 1) - 1)) : 0.0;
+    const int nsub = (b + NB - 1) / NB;
+    for (int tt = nsub - 1; tt >= 0; --tt) {
+        const bool above = BIG && wave < tt && bw > 0;
+        const int bt = min(NB, b - NB * tt);            // rows of sub-block tt
+        double blk[BIG ? NB : 1];                       // L(rows of sub-block tt, this lane's column): one contiguous run
+        if (BIG && above) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) blk[k] = P[(t.diag + NB * tt + min(k, bt - 1)) + (int64_t)(t.diag + o + min(lane, bw - 1)) * ld];
+        }
+        if (wave == tt) {
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
+                if (lane == j) v = xj;
+                if (lane < j) v -= bcol[j] * xj;           // D(j, lane) * x_j
+            }
+            xs[o + lane] = (lane < bw) ? v : 0.0;
+        }
+        if (BIG) {
+            __syncthreads();
+            if (above) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) v -= blk[k] * xs[NB * tt + k];       // rows beyond bt meet xs = 0
+            }
+        }
+    }
+    if (lane < bw) xq[lane] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Steps in which every panel is narrow (nscol <= 64: the swarm levels, tens of thousands of supernodes of a few dozen
+// columns): ONE WAVE per supernode does its whole part of the sweep -- diagonal solve and all its rows -- with no hand-off,
+// four supernodes per workgroup.  (Through the general kernels such a supernode costs a diagonal workgroup plus one workgroup
+// per 64 rows, three of four waves idle in each, and a device-scope hand-off.)  task.ld = nsrow, task.b = nscol.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+k_solve_small_fwd(const SolveTask* __restrict__ tasks, int ntasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
+                  double* __restrict__ x, int unit, const int32_t* __restrict__ pivpos) {
+    __shared__ double ptmp[4][NB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the task index is uniform over the wave: say so, or every field of the task (and all address arithmetic) lives in VGPRs
+    const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (ti >= ntasks) return;
+    const SolveTask t = tasks[ti];
+    const int b = t.b;
+    const int64_t ld = t.ld;
+    const double* P = Lsx + t.panel;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const double v = P[min(lane, b - 1) + (int64_t)min(c, b - 1) * ld];
+        a[c] = (lane < b && c + unit <= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+    }
+    double* xq = x + t.first_col;
+    double v = (lane < b) ? xq[lane] : 0.0;
+    if (pivpos) {
+        if (lane < b) ptmp[wave][pivpos[t.first_col + lane] - t.first_col] = v;
+        v = (lane < b) ? ptmp[wave][lane] : 0.0;
+    }
+    double dinv = 1.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) dinv = (c == lane) ? 1.0 / a[c] : dinv;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
+        if (lane == j) v = xj;
+        if (lane > j) v -= a[j] * xj;
+    }
+    if (lane < b) xq[lane] = v;
+    // the rows below: 64 at a time, lane = row; x_blk[k] is broadcast out of lane k's register
+    for (int r0 = b; r0 < (int)ld; r0 += NB) {
+        const int row = min(r0 + lane, (int)ld - 1);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) a[k] = P[row + (int64_t)min(k, b - 1) * ld];
+        const int32_t gi = Lsi[t.rows + row];
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc += a[k] * readlane_f64(v, k);       // lanes >= b hold v = 0
+        if (r0 + lane < (int)ld) unsafeAtomicAdd(x + gi, -acc);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_solve_small_bwd(const SolveTask* __restrict__ tasks, int ntasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
+                  double* __restrict__ x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (ti >= ntasks) return;
+    const SolveTask t = tasks[ti];
+    const int b = t.b;
+    const int64_t ld = t.ld;
+    const double* P = Lsx + t.panel;
+    // s_c = sum over the rows below of L(row, c) x[row]: lane = row (coalesced), then the transposing butterfly
+    double s = 0.0;
+    double p[NB];
+    for (int r0 = b; r0 < (int)ld; r0 += NB) {
+        const int row = min(r0 + lane, (int)ld - 1);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] = P[row + (int64_t)min(k, b - 1) * ld];
+        const double xr = (r0 + lane < (int)ld) ? x[Lsi[t.rows + row]] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] *= xr;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+                const double keep = up ? p[i + m] : p[i];
+                const double give = up ? p[i] : p[i + m];
+                p[i] = keep + __shfl_xor(give, m, 64);
+            }
+        }
+        s += p[0];
+    }
+    // D^T x_blk = x_blk - s, lane = column
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const double v = P[min(c, b - 1) + (int64_t)min(lane, b - 1) * ld];
+        p[c] = (lane < b && c < b && c >= lane) ? v : ((c == lane) ? 1.0 : 0.0);
+    }
+    double dinv = 1.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) dinv = (c == lane) ? 1.0 / p[c] : dinv;
+    double* xq = x + t.first_col;
+    double v = (lane < b) ? xq[lane] - s : 0.0;
 #pragma unroll
     for (int j = NB - 1; j >= 0; --j) {
         const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
         if (lane == j) v = xj;
-        if (lane < j) v -= bcol[j] * xj;           // D(j, lane) * x_j
+        if (lane < j) v -= p[j] * xj;
     }
     if (lane < b) xq[lane] = v;
 }
 
-void launch_solve_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
-                      int* sync, int* ticket, int* info, hipStream_t st) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_fwd, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, unit, pivpos, sync, ticket, info);
+void launch_solve_small_fwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
+                            hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_small_fwd, dim3((nt + 3) / 4), dim3(256), 0, st, t, nt, Lsx, Lsi, x, unit, pivpos);
 }
-void launch_solve_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
+void launch_solve_small_bwd(const SolveTask* t, int nt, const double* Lsx, const int32_t* Lsi, double* x, hipStream_t st) {
+    if (nt > 0) hipLaunchKernelGGL(k_solve_small_bwd, dim3((nt + 3) / 4), dim3(256), 0, st, t, nt, Lsx, Lsi, x);
+}
+
+void launch_solve_fwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
+                      int* sync, int* ticket, int* info, hipStream_t st) {
+    if (nt <= 0) return;
+    if (big) hipLaunchKernelGGL(k_solve_fwd<true>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, unit, pivpos, sync, ticket, info);
+    else hipLaunchKernelGGL(k_solve_fwd<false>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, unit, pivpos, sync, ticket, info);
+}
+void launch_solve_bwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
                       hipStream_t st) {
-    if (nt > 0) hipLaunchKernelGGL(k_solve_bwd, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info);
+    if (nt <= 0) return;
+    if (big) hipLaunchKernelGGL(k_solve_bwd<true>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info);
+    else hipLaunchKernelGGL(k_solve_bwd<false>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1236,7 +1418,8 @@ __global__ void __launch_bounds__(256)
 k_update_small(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks, int ntasks,
                double* __restrict__ Lsx, const int32_t* __restrict__ RelMap) {
     const int lane = threadIdx.x & 63;
-    const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // uniform over the wave: say so, or the task, the problem and all address arithmetic live in VGPRs
+    const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (ti >= ntasks) return;
     const GemmTask tk = tasks[ti];
     const GemmProb pb = probs[tk.prob];

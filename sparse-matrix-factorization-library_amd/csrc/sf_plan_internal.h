@@ -134,8 +134,9 @@ struct sf_chol_plan {
     // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
     sf::SolveTask* d_solve = nullptr;
     double* d_x = nullptr;
-    struct SolveStep { int64_t fwd_first, bwd_first; int count; };   // both launches of a step have `count` tasks
+    struct SolveStep { int64_t fwd_first, bwd_first; int count; int big; int nrows_tasks; int small; int ndiag; };   // both launches of a step have `count` tasks; big: a panel of the step is wider than 64 columns
     int* d_solve_sync = nullptr;
+    bool solve_bwd_fused = false;
     int n_solve_sync = 0;
     std::vector<SolveStep> solve_steps;
     double last_solve_ms = 0;
