@@ -983,13 +983,16 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 // (16 consecutive rows x 4 k per load), 32 k ahead in registers, no LDS staging and no barriers in the K loop.
 // The updated 64 x 64 tile then goes to LDS (U[column][row]) where the POTRF wave / the blocked solve picks it up.
 // ---------------------------------------------------------------------------------------------------
+#ifndef SF_LU_STEP_WGS
+#define SF_LU_STEP_WGS 2      // workgroups per CU the LU variant of k_step is compiled for (experiment knob)
+#endif
 constexpr int ST_ULD = ST_ROWS + 1;      // LDS column stride of the updated tile U[c][r]
 constexpr int ST_KC = 32;                // K chunk of the update's LDS-staged operand
 constexpr int ST_XLD = ST_ROWS + 16;     // its LDS row stride
 constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 
 template <bool LU>
-__global__ void __launch_bounds__(256, LU ? 2 : 3)   // LU: the unblocked GETRF keeps a 64-value row per lane
+__global__ void __launch_bounds__(256, LU ? SF_LU_STEP_WGS : 3)   // LU: the unblocked GETRF keeps a 64-value row per lane
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info,
        double* __restrict__ tinv, int* __restrict__ ticket, PivotCtl pc) {
     // ONE LDS array, re-used by the phases of a task:

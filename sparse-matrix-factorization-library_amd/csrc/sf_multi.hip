@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -120,7 +121,7 @@ struct sf_comm {
     LocalGroup* local = nullptr;
     // sub-communicators of the groups of a proportionally mapped factorization, by the mask of WORLD ranks they hold
     std::vector<std::pair<uint32_t, sf_comm*>> subs;
-    bool groups_ready = false;
+    std::vector<uint32_t> prepared;     // every mask a collective split has been made for (member or not)
 };
 
 namespace {
@@ -212,14 +213,17 @@ int sf_comm_create_all(sf_comm** comms, int nranks, const int* devices) {
 
 // Sub-communicators for the groups `masks` (bit r = world rank r; the same sorted list on every rank).  Collective: every
 // rank of `c` calls it with the same list -- ncclCommSplit per group for RCCL (a rank outside a group passes
-// NCCL_SPLIT_NOCOLOR), a shared LocalGroup per mask for emulated ranks.  Idempotent.
+// NCCL_SPLIT_NOCOLOR), a shared LocalGroup per mask for emulated ranks.  Masks met in an earlier call are skipped.
 int sf_comm_prepare_groups(sf_comm* c, const uint32_t* masks, int nmasks) {
     if (!c || (nmasks > 0 && !masks)) return SF_ERR_ARG;
-    if (c->groups_ready) return SF_OK;
     const uint32_t all = c->nranks >= 32 ? 0xffffffffu : ((1u << c->nranks) - 1u);
     for (int k = 0; k < nmasks; ++k) {
         const uint32_t m = masks[k] & all;
         if (m == all || m == 0) continue;                       // the world itself / nobody
+        // a mask met before (another plan with the same groups) needs no second split; every rank keeps the same list, so
+        // the collective calls still match up
+        if (std::find(c->prepared.begin(), c->prepared.end(), m) != c->prepared.end()) continue;
+        c->prepared.push_back(m);
         const bool mine = ((m >> c->rank) & 1u) != 0;
         const int gsize = __builtin_popcount(m), grank = __builtin_popcount(m & ((1u << c->rank) - 1u));
         if (c->kind == 0) {
@@ -247,7 +251,6 @@ int sf_comm_prepare_groups(sf_comm* c, const uint32_t* masks, int nmasks) {
             c->subs.push_back({m, sc});
         }
     }
-    c->groups_ready = true;
     return SF_OK;
 }
 

@@ -140,3 +140,25 @@ def test_mapped_plans_store_less_and_group_their_segments():
         pr.close()
     assert len(groups) >= 3                             # nested groups: pairs, quads, all
     assert max(stored_mapped) < 0.9 * max(stored_repl)
+
+
+def test_one_handler_list_two_patterns_emulated(oracle, monkeypatch):
+    """two matrices with different elimination trees through ONE handler list: the second one's groups of ranks are not the
+    first one's, their sub-communicators are made when it arrives; both plans stay cached"""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", "4")
+    common = sf.CommonInfo(dev_slot_size=8 << 30)
+    for dims in ((20, 20, 20), (40, 30, 6), (20, 20, 20)):
+        n, Cp, Ci, Cx = gen.laplacian_lower(*dims)
+        perm = sf.grid_nd_perm(*dims)
+        sym = sf.analyze(n, Cp, Ci, Cx, perm, 8 << 30)
+        ref, info, _ = oracle.chol_factorize(sym)
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        mi.factorize(common)
+        assert rel_err(mi.array("Lsx", sym.xsize).copy(), ref, oracle.lower_mask(sym)) <= TOL_FACTOR
+        mi.cleanup()
+    common.close()
