@@ -745,6 +745,20 @@ __device__ __forceinline__ int last_le_u32(const uint32_t* __restrict__ a, int n
 // zeros (a DMA cannot mask), rows beyond M / N read valid memory whose products only reach entries that are never stored.
 __device__ double g_zero_page[GEMM_BM + 16];
 
+// One LDS-DMA of 16 bytes per lane (1 KiB per wave) as inline asm: the builtin form makes hipcc wait vmcnt(0) before the NEXT
+// ds_read (it cannot tell the DMA's LDS destination from the buffer being read), which exposes the whole memory latency once per
+// K step; an asm statement is outside its s_waitcnt bookkeeping, so the DMA stays in flight until the explicit
+// `s_waitcnt vmcnt(0)` in front of the K step's barrier.  (Untracked operations can only make hipcc's own counted waits
+// stricter: vmcnt retires in order.)  M0 = the wave-uniform LDS byte address, saved and restored around the instruction.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
+}
+
 template <int MODE, bool DMA>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
@@ -866,8 +880,8 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                     const bool kin = k < K;                                     // wave-uniform
                     const double* ysrc = yp + (int64_t)min(k, K - 1) * lda;
                     const double* xsrc = kin ? xp + (int64_t)k * lda : g_zero_page + prow;
-                    __builtin_amdgcn_global_load_lds((const void*)ysrc, (__attribute__((address_space(3))) void*)&Ys[buf][kl][0], 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const void*)xsrc, (__attribute__((address_space(3))) void*)&Xs[buf][kl][0], 16, 0, 0);
+                    glds16(ysrc, lds_addr(&Ys[buf][kl][0]));
+                    glds16(xsrc, lds_addr(&Xs[buf][kl][0]));
                 }
                 return;
             }
@@ -898,6 +912,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         // the shadow of this wave's own MFMAs (an MFMA occupies the matrix pipe for 64 cycles after it issues).
         load_tile(kt0 * GEMM_BK);
         store_tile(0, kt0 * GEMM_BK);
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         load_tile((kt0 + 1) * GEMM_BK);
         int buf = 0;
@@ -918,6 +933,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                         for (int tn = 0; tn < 4; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
                 }
+                if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next K step's tile has landed
                 __syncthreads();
                 buf ^= 1;
             }
@@ -925,6 +941,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
             for (int kt = kt0; kt < kt1; ++kt) {     // staging only, same barriers
                 store_tile(buf ^ 1, (kt + 1) * GEMM_BK);
                 load_tile((kt + 2) * GEMM_BK);
+                if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 buf ^= 1;
             }
