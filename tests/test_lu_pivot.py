@@ -128,3 +128,40 @@ def test_struct_entry_points_with_interchanges():
     assert mi.validate() <= 1e-10
     mi.cleanup()
     common.close()
+
+
+def test_interchanges_in_shared_top_panels_emulated_ranks(monkeypatch):
+    """two emulated handlers: exact zeros on the diagonal inside the TOP supernodes, whose 64-column chains run replicated
+    on both ranks after the all-reduce -- both must take the same pivots (their inputs are bit-identical), the factor pieces
+    come back from different ranks, PivInv is assembled from both, and the host solve must still reproduce b"""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", "2")
+    N = 12
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=31)
+    perm = nd_perm_py(N, N, N)
+    S0 = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    owner, _, _ = sf.subtree_partition(S0, 2, 0.75)
+    tops = [s for s in range(S0.nsuper) if owner[s] < 0]
+    assert tops
+    Cx = Cx.copy()
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    zeroed = 0
+    for s in tops:
+        for j in range(S0.Super[s], S0.Super[s + 1], 37):         # a few columns of every top supernode, never two in a row
+            g = S0.Perm[j]
+            Cx[(Ci == g) & (cols == g)] = 0.0
+            zeroed += 1
+    assert zeroed >= 3
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    assert common.c.numGPU == 2
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    mi.factorize(common)
+    piv = mi.array("PivInv", n)
+    assert sorted(piv.tolist()) == list(range(n)) and np.count_nonzero(piv != np.arange(n)) >= 2
+    assert mi.validate() <= 1e-10
+    mi.cleanup()
+    common.close()
