@@ -43,38 +43,55 @@ class HipEngine:
         if self.lu and world > 1 and not self.distributed:
             raise ValueError("sharded LU needs mode='distributed'")
         cls = LUPlan if self.lu else CholPlan
-        use_c_comm = False
-        if self.distributed:
-            import torch.distributed as dist
-            use_c_comm = dist.is_initialized() and dist.get_backend(group) == "nccl" and dist.get_world_size(group) == world
-        if self.lu and world == 1:
-            self.plan = LUPlan(sym, device=device)
-        elif use_c_comm and owner is not None:
-            # the product path: proportionally mapped plan (a top supernode lives on the ranks below it), groups and their
-            # collectives handled by the C library
-            self.plan = cls(sym, device=device, owner=owner, rank=rank, nranks=world)
-        else:
-            self.plan = cls(sym, device=device, phase=phase, load_top=load_top,
-                            rank=rank if self.distributed else 0, nranks=world if self.distributed else 1)
         self.device = device
         self._top = None
         self._seg = {}
         self.comm = None
+        self.comm_kind = "none"
         if self.distributed:
+            import os
             import torch
             import torch.distributed as dist
-            if dist.is_initialized() and dist.get_backend(group) == "nccl" and dist.get_world_size(group) == world:
+            want_c = (dist.is_initialized() and dist.get_backend(group) == "nccl" and dist.get_world_size(group) == world
+                      and owner is not None and os.environ.get("SF_BENCH_COMM", "rccl-c") != "torch")
+            if want_c:
                 # the product path: the collectives are issued by the C library itself (RCCL on the plan's stream,
-                # sf_chol_plan_factorize_distributed); torch.distributed only carries the 128-byte unique id
+                # sf_chol_plan_factorize_distributed); torch.distributed only carries the 128-byte unique id.  Every rank
+                # reports whether its communicator came up; unless all did, all fall back to torch's collectives together.
                 from .api import Comm
-                uid = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{device}")
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8))
-                dist.broadcast(uid, 0, group=group)
-                self.comm = Comm(device, rank, world, bytes(uid.cpu().numpy().tobytes()))
-            else:
-                # rehearsals (gloo: several ranks on one GPU): the collective is torch's, so run on the stream it is ordered with
+                ok = 1
+                try:
+                    uid = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{device}")
+                    if rank == 0:
+                        uid.copy_(torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8))
+                    dist.broadcast(uid, 0, group=group)
+                    self.comm = Comm(device, rank, world, bytes(uid.cpu().numpy().tobytes()))
+                except Exception as e:          # noqa: BLE001 -- any failure here means "use the torch path"
+                    import sys
+                    print(f"[sparseframe-hip] rank {rank}: C-side RCCL communicator unavailable ({e}); falling back to torch.distributed",
+                          file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if int(flag.item()) == 0 and self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+        if self.lu and world == 1:
+            self.plan = LUPlan(sym, device=device)
+        elif self.comm is not None:
+            # proportionally mapped plan (a top supernode lives on the ranks below it), groups and their collectives handled by
+            # the C library
+            self.plan = cls(sym, device=device, owner=owner, rank=rank, nranks=world)
+            self.comm_kind = "rccl-c"
+        else:
+            self.plan = cls(sym, device=device, phase=phase, load_top=load_top,
+                            rank=rank if self.distributed else 0, nranks=world if self.distributed else 1)
+            if self.distributed:
+                # the collective is torch's (gloo rehearsals with several ranks on one GPU; the fallback of the nccl path): run
+                # on the stream it is ordered with
+                import torch
                 self.plan.set_stream(torch.cuda.current_stream(device).cuda_stream)
+                self.comm_kind = "torch"
 
     def set_values(self, Lx, Ux=None):
         if self.lu:
@@ -147,7 +164,7 @@ class ShardedFactorization:
     def plan_info(self):
         tf, ml = self.top_fraction, self.max_load_fraction
         cost = self.top_weight * tf + ml
-        return {"mode": self.mode,
+        return {"mode": self.mode, "collectives": getattr(self.engine, "comm_kind", "engine"),
                 "subtrees_per_rank": [int(np.count_nonzero(self.owner == r)) for r in range(self.world)],
                 "top_supernodes": int(np.count_nonzero(self.owner < 0)),
                 "top_flop_fraction": tf, "max_rank_subtree_flop_fraction": ml,
