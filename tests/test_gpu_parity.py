@@ -466,3 +466,42 @@ def test_gemm_register_staged_form(oracle, monkeypatch):
         plan, Lsx = gpu_factor(sym)
         plan.close()
         assert rel_err(Lsx, ref, mask) <= TOL_FACTOR, dma
+
+
+def test_two_matrix_threads_share_one_handler_list(oracle):
+    """the reference's driver runs MATRIX_THREAD_NUM = 2 matrices at a time over ONE gpu_info_list (SparseFrame.c:3371-3375):
+    two host threads call SparseFrame_factorize concurrently (ctypes releases the GIL); the handler's lock serialises them,
+    both patterns stay cached, both factors are right"""
+    import threading
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    cases = []
+    for dims in ((14, 14, 14), (60, 50, 1)):
+        n, Cp, Ci, Cx = gen.laplacian_lower(*dims)
+        perm = sf.grid_nd_perm(*dims)
+        sym = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
+        ref, info, _ = oracle.chol_factorize(sym)
+        cases.append((n, Cp, Ci, Cx, perm, sym, ref, oracle.lower_mask(sym)))
+    errors = []
+
+    def work(k, serial):
+        n, Cp, Ci, Cx, perm, sym, ref, mask = cases[k]
+        try:
+            for rep in range(3):
+                mi = sf.MatrixInfo(serial=serial)
+                mi.set_csc(n, Cp, Ci, Cx)
+                mi.set_perm(perm)
+                mi.analyze(common)
+                mi.factorize(common)
+                if rel_err(mi.array("Lsx", sym.xsize).copy(), ref, mask) > TOL_FACTOR:
+                    errors.append((k, rep))
+                mi.cleanup()
+        except Exception as e:      # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k, k)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    common.close()
+    assert not errors, errors
