@@ -22,6 +22,7 @@
 #include <sparseframe_hip.h>
 
 #include <algorithm>
+#include <time.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -173,6 +174,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     if (load_top != 1) p->partial = true;
     const int64_t ushift = p->xC;     // PU(s) = PL(s) + ushift
 
+    const bool trace_pc = getenv("SF_TRACE") != nullptr;
+    auto pc_now = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec / 1e6; };
+    const double pc_t0 = pc_now();
     // ---------------- validate the structure the kernels index with ----------------
     for (sf_long s = 0; s < nsuper; ++s) {
         const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
@@ -218,6 +222,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
     }
 
+    const double pc_t1 = pc_now();
     // ---------------- task tables ----------------
     std::vector<PotrfTask> potrf;
     std::vector<TrsmTask> trsm;
@@ -534,6 +539,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
     p->n_gemm_tasks = (int64_t)gtasks.size() + (int64_t)stasks.size();
 
+    const double pc_t2 = pc_now();
     // ---------------- device solve schedule (unsharded plans) ----------------
     // per (level, SV_B-column step): a forward launch [diagonal tasks, SV_ROWS-row tiles] and a backward launch [tiles, diagonal tasks]
     std::vector<sf::SolveTask> solve;
@@ -678,6 +684,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
     }
 
+    const double pc_t3 = pc_now();
     // ---------------- upload ----------------
     std::vector<int32_t> Li32(p->nnz), Super32(nsuper + 1), SuperMap32(n), Lsi32(p->isize);
     for (sf_long k = 0; k < p->nnz; ++k) Li32[k] = (int32_t)Li[k];
@@ -790,6 +797,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         p->bytes_device += xb + vb + (1 + p->n_tickets) * sizeof(int);
     } while (0);
     if (rc) { sf_chol_plan_destroy(p); return rc; }
+    if (trace_pc)
+        fprintf(stderr, "[sparseframe-hip] plan_create: validate + levels %.1f ms, task tables %.1f ms, solve + download schedules + K prefixes %.1f ms, "
+                        "uploads + relative maps + allocations %.1f ms\n", pc_t1 - pc_t0, pc_t2 - pc_t1, pc_t3 - pc_t2, pc_now() - pc_t3);
     *out = p;
     return SF_OK;
 }
