@@ -12,6 +12,9 @@
 // The code is organised differently (separate passes over std::vector, no shared workspace
 // aliasing) but each pass is written to reproduce the reference's tie-breaking exactly.
 #include "sf_symbolic.h"
+#include <time.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
@@ -272,7 +275,11 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     for (Long p = 0; p < Cp[n]; ++p)
         if (Ci[p] < 0 || Ci[p] >= n) return 1;
 
+    const bool tr_ = getenv("SF_TRACE") != nullptr;
+    auto now_ = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec / 1e6; };
+    double tm_[8]; tm_[0] = now_();
     build_triangles(n, Cp, Ci, Cx, Perm, S);
+    tm_[1] = now_();
 
     std::vector<Long> Parent, Post, Count;
     elimination_tree(S, Parent);
@@ -280,6 +287,7 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     column_counts(S, Parent, Post, Count);
     postorder(Parent, &Count, Post);
 
+    tm_[2] = now_();
     S.Post = Post;
     S.Parent0 = Parent;
     S.ColCount0 = Count;
@@ -295,6 +303,7 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
         S.ColCount[k] = Count[old];
     }
     build_triangles(n, Cp, Ci, Cx, S.Perm, S);
+    tm_[3] = now_();
 
     const std::vector<Long>& Par = S.Parent;
     const std::vector<Long>& CC = S.ColCount;
@@ -382,6 +391,7 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     S.isize = S.Lsip[ns];
     S.xsize = S.Lsxp[ns];
 
+    tm_[4] = now_();
     // ---- row structure: own columns, then every row j that reaches the supernode through
     //      the supernodal tree from the supernode of a nonzero (j,i), i<=j (C:1660-1692) ----
     S.Lsi.assign(S.isize, -1);
@@ -409,6 +419,7 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
             if (fill[s] != S.Lsip[s + 1]) return 2;
     }
 
+    tm_[5] = now_();
     // ---- csize: largest update block any descendant->ancestor pair needs (C:1694-1719) ----
     S.csize = 0;
     for (Long s = 0; s < ns; ++s) {
@@ -517,6 +528,10 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
         }
         for (Long k = S.ST_Pointer[st]; k < S.ST_Pointer[st + 1]; ++k) S.Moffset[S.ST_Index[k]] += (Long)asz;
     }
+    if (tr_)
+        fprintf(stderr, "[sparseframe-hip] analyze: triangles %.1f ms, etree + postorder + column counts %.1f ms, renumber + triangles %.1f ms, "
+                        "supernodes %.1f ms, row structure %.1f ms, csize + stages + offsets %.1f ms\n", tm_[1] - tm_[0], tm_[2] - tm_[1],
+                tm_[3] - tm_[2], tm_[4] - tm_[3], tm_[5] - tm_[4], now_() - tm_[5]);
     return 0;
 }
 
