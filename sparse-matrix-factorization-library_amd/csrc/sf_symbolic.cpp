@@ -12,6 +12,7 @@
 // The code is organised differently (separate passes over std::vector, no shared workspace
 // aliasing) but each pass is written to reproduce the reference's tie-breaking exactly.
 #include "sf_symbolic.h"
+#include <thread>
 #include <time.h>
 #include <cstdio>
 #include <cstdlib>
@@ -88,33 +89,41 @@ void build_triangles(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     S.Li.resize(nz);  S.Lx.resize(nz);
     S.LTi.resize(nz); S.LTx.resize(nz);
 
-    for (Long j = 0; j < n; ++j) {
-        const Long jold = Perm[j];
-        if (jold < 0) continue;
-        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
-            const Long i = Pinv[Ci[p]];
-            S.Lp[std::min(i, j) + 1]++;
-            S.LTp[std::max(i, j) + 1]++;
+    // L (by column) and L^T (by row) are two independent bucket sorts of the same entry stream, each filled in the traversal
+    // order of C:1036-1063: one host thread each (the scattered writes are latency-bound, the two do not share a cache line)
+    auto build = [&](bool transpose) {
+        std::vector<Long>& P = transpose ? S.LTp : S.Lp;
+        std::vector<Long>& I = transpose ? S.LTi : S.Li;
+        std::vector<double>& X = transpose ? S.LTx : S.Lx;
+        for (Long j = 0; j < n; ++j) {
+            const Long jold = Perm[j];
+            if (jold < 0) continue;
+            for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
+                const Long i = Pinv[Ci[p]];
+                P[(transpose ? std::max(i, j) : std::min(i, j)) + 1]++;
+            }
         }
-    }
-    for (Long j = 0; j < n; ++j) {
-        S.Lp[j + 1] += S.Lp[j];
-        S.LTp[j + 1] += S.LTp[j];
-    }
-    std::vector<Long> lnext(S.Lp.begin(), S.Lp.end() - 1), tnext(S.LTp.begin(), S.LTp.end() - 1);
-    for (Long j = 0; j < n; ++j) {
-        const Long jold = Perm[j];
-        if (jold < 0) continue;
-        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
-            const Long i = Pinv[Ci[p]];
-            const Long lo = std::min(i, j), hi = std::max(i, j);
-            const Long lp = lnext[lo]++;
-            S.Li[lp] = hi;
-            S.Lx[lp] = Cx ? Cx[p] : 0.0;
-            const Long tp = tnext[hi]++;
-            S.LTi[tp] = lo;
-            S.LTx[tp] = Cx ? Cx[p] : 0.0;
+        for (Long j = 0; j < n; ++j) P[j + 1] += P[j];
+        std::vector<Long> next(P.begin(), P.end() - 1);
+        for (Long j = 0; j < n; ++j) {
+            const Long jold = Perm[j];
+            if (jold < 0) continue;
+            for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
+                const Long i = Pinv[Ci[p]];
+                const Long lo = std::min(i, j), hi = std::max(i, j);
+                const Long q = next[transpose ? hi : lo]++;
+                I[q] = transpose ? lo : hi;
+                X[q] = Cx ? Cx[p] : 0.0;
+            }
         }
+    };
+    if (nz > (Long)1 << 16) {
+        std::thread t(build, true);
+        build(false);
+        t.join();
+    } else {
+        build(false);
+        build(true);
     }
 }
 
