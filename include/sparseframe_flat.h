@@ -120,6 +120,9 @@ int sf_chol_plan_factorize_to_host(sf_chol_plan *plan, const sf_float *Lx, const
 void *sf_chol_plan_factor_device_ptr(sf_chol_plan *plan);
 /* device-side supernodal solve with the resident factor: x <- (L L^T)^{-1} b, permuted space */
 int sf_chol_plan_solve(sf_chol_plan *plan, const sf_float *b_host, sf_float *x_host);
+/* SparseFrame_validate on the device (C:3141-3266; LU plans: L:3702-3858): b_i = 1 + i/n, solve with the resident factor,
+ * r = A x - b from the plan's copy of the matrix values, *residual = |r|_inf / (|A|_1 |x|_inf + |b|_inf).  x_host may be NULL. */
+int sf_chol_plan_validate(sf_chol_plan *plan, sf_float *residual, sf_float *x_host);
 /* statistics: "levels","launches","gemm_tasks","update_pairs","flops_exec","flops_update",
  * "scatter_elems","bytes_device","last_ms" (device time of the last factorize, HIP events),
  * "last_update_ms","last_panel_ms","last_load_ms" (only when profiling is on) */

@@ -269,7 +269,16 @@ class _ShardedPlanMixin:
         return lib.sf_chol_plan_factor_device_ptr(self._h)
 
 
-class CholPlan(_ShardedPlanMixin):
+class _ValidateMixin:
+    def validate(self, return_x=False):
+        """SparseFrame_validate on the device: b_i = 1 + i/n, solve, residual |Ax - b|_inf / (|A|_1 |x|_inf + |b|_inf)"""
+        res = C.c_double()
+        x = np.empty(max(self.n, 1), dtype=np.float64) if return_x else None
+        check(lib.sf_chol_plan_validate(self._h, C.byref(res), _dp(x) if return_x else None), "sf_chol_plan_validate")
+        return (res.value, x[:self.n]) if return_x else res.value
+
+
+class CholPlan(_ShardedPlanMixin, _ValidateMixin):
     """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present.
     phase/load_top: multi-GPU sharding (sf_chol_plan_create_sharded); default = the whole matrix on one device.
     rank/nranks (with phase): distributed top (sf_chol_plan_create_distributed), run with factorize_phase(0) and then
@@ -351,7 +360,7 @@ class CholPlan(_ShardedPlanMixin):
         self.close()
 
 
-class LUPlan(_ShardedPlanMixin):
+class LUPlan(_ShardedPlanMixin, _ValidateMixin):
     """Device-resident supernodal no-pivot LU (flat ABI, sf_lu_plan_*).  `sym` comes from analyze(..., method='lu').
     phase/load_top/rank/nranks: distributed multi-GPU plan (sf_lu_plan_create_distributed), as CholPlan."""
 

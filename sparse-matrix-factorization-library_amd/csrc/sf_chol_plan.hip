@@ -63,7 +63,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1141,6 +1141,37 @@ int sf_chol_plan_set_stream(sf_chol_plan* p, void* stream) {
 
 
 int sf_chol_plan_factorize(sf_chol_plan* p, int sync) { return sf_chol_plan_factorize_phase(p, -1, sync); }
+
+// The whole of SparseFrame_validate on the device (C:3141-3266, L:3702-3858): b_i = 1 + i/n, the supernodal solve with the
+// resident factor, r = A x - b from the plan's copy of the matrix, residual = |r|_inf / (|A|_1 |x|_inf + |b|_inf).  Nothing
+// but the scalar comes back (x_host may be NULL).
+int sf_chol_plan_validate(sf_chol_plan* p, sf_float* residual, sf_float* x_host) {
+    if (!p || !residual) return SF_ERR_ARG;
+    if (p->partial || (p->nsuper > 0 && !p->d_solve) || !p->values_set) return SF_ERR_ARG;
+    *residual = 0.0;
+    if (p->n <= 0) return SF_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->d_resid) {
+        HIP_TRY(hipMalloc((void**)&p->d_resid, (3 * (size_t)p->n + 4) * sizeof(double)));
+        p->bytes_device += (3 * (size_t)p->n + 4) * sizeof(double);
+    }
+    std::vector<double> b(p->n), x(p->n);
+    for (int64_t i = 0; i < p->n; ++i) b[i] = 1.0 + (double)i / (double)p->n;
+    int rc = sf_chol_plan_solve(p, b.data(), x.data());          // leaves the solution in d_x
+    if (rc) return rc;
+    double* r = p->d_resid, *colsum = r + p->n, *bb = colsum + p->n, *norms = bb + p->n;
+    HIP_TRY(hipMemsetAsync(norms, 0, 4 * sizeof(double), p->stream));
+    const bool unsym = p->lu && !p->u_alias;
+    sf::launch_residual(p->d_Lp, p->d_Li, p->d_Lx, unsym ? p->d_Up : nullptr, unsym ? p->d_Ui : nullptr, unsym ? p->d_Ux : nullptr,
+                        (int32_t)p->n, p->d_x, r, colsum, bb, norms, p->stream);
+    HIP_TRY(hipGetLastError());
+    double h[4];
+    HIP_TRY(hipMemcpyAsync(h, norms, sizeof(h), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    *residual = h[0] / (h[1] * h[2] + h[3]);
+    if (x_host) memcpy(x_host, x.data(), p->n * sizeof(double));
+    return SF_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Overlapped copy-back.  The reference copies finished blocks back on a second stream while it computes

@@ -1515,6 +1515,87 @@ void launch_update_small(const GemmProb* probs, const GemmTask* tasks, int ntask
     hipLaunchKernelGGL(k_update_small, dim3((ntasks + 3) / 4), dim3(256), 0, st, probs, tasks, ntasks, Lsx, RelMap);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// On-device validation (the device twin of SparseFrame_validate, C:3141-3266 / L:3702-3858): r = A x - b with the stored
+// triangle(s) of P A P^T, then |r|_inf / (|A|_1 |x|_inf + |b|_inf).  One lane per column (row for U); the four maxima are
+// taken with integer atomicMax on the bit patterns (non-negative doubles order like unsigned integers).
+//   norms[0] = |r|_inf, [1] = |A|_1 (max column sum), [2] = |x|_inf, [3] = |b|_inf
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_resid_init(int32_t n, double* __restrict__ r, double* __restrict__ colsum, double* __restrict__ b_out) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double b = 1.0 + (double)i / (double)n;
+    b_out[i] = b;
+    r[i] = -b;
+    colsum[i] = 0.0;
+}
+
+// sym != 0: (Lp, Li, Lx) is one triangle of a symmetric matrix, used for both (Cholesky; LU of a symmetric input);
+// sym == 0: only its own entries (the L part by column of an unsymmetric matrix)
+__global__ void __launch_bounds__(256)
+k_resid_cols(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, const double* __restrict__ Lx, int32_t n, int sym,
+             const double* __restrict__ x, double* __restrict__ r, double* __restrict__ colsum) {
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double xj = x[j];
+    double rj = 0.0, cj = 0.0;
+    for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) {
+        const int32_t i = Li[p];
+        const double a = Lx[p];
+        unsafeAtomicAdd(r + i, a * xj);
+        cj += fabs(a);
+        if (sym && i != j) {
+            rj += a * x[i];
+            unsafeAtomicAdd(colsum + i, fabs(a));
+        }
+    }
+    if (rj != 0.0) unsafeAtomicAdd(r + j, rj);
+    unsafeAtomicAdd(colsum + j, cj);
+}
+
+// U by ROW (unsymmetric LU): row i lists columns j >= i; the diagonal is already in the L part
+__global__ void __launch_bounds__(256)
+k_resid_urows(const int64_t* __restrict__ Up, const int32_t* __restrict__ Ui, const double* __restrict__ Ux, int32_t n,
+              const double* __restrict__ x, double* __restrict__ r, double* __restrict__ colsum) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double ri = 0.0;
+    for (int64_t p = Up[i]; p < Up[i + 1]; ++p) {
+        const int32_t j = Ui[p];
+        if (j == i) continue;
+        ri += Ux[p] * x[j];
+        unsafeAtomicAdd(colsum + j, fabs(Ux[p]));
+    }
+    if (ri != 0.0) unsafeAtomicAdd(r + i, ri);
+}
+
+__global__ void __launch_bounds__(256)
+k_resid_norms(int32_t n, const double* __restrict__ r, const double* __restrict__ colsum, const double* __restrict__ x,
+              const double* __restrict__ b, unsigned long long* __restrict__ norms) {
+    double m[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        m[0] = fmax(m[0], fabs(r[i])); m[1] = fmax(m[1], colsum[i]); m[2] = fmax(m[2], fabs(x[i])); m[3] = fmax(m[3], fabs(b[i]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = m[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(norms + k, (unsigned long long)__double_as_longlong(v));
+    }
+}
+
+void launch_residual(const int64_t* Lp, const int32_t* Li, const double* Lx, const int64_t* Up, const int32_t* Ui, const double* Ux,
+                     int32_t n, const double* x, double* r, double* colsum, double* b, double* norms, hipStream_t st) {
+    if (n <= 0) return;
+    const int g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_resid_init, dim3(g), dim3(256), 0, st, n, r, colsum, b);
+    hipLaunchKernelGGL(k_resid_cols, dim3(g), dim3(256), 0, st, Lp, Li, Lx, n, Up ? 0 : 1, x, r, colsum);
+    if (Up) hipLaunchKernelGGL(k_resid_urows, dim3(g), dim3(256), 0, st, Up, Ui, Ux, n, x, r, colsum);
+    hipLaunchKernelGGL(k_resid_norms, dim3(g < 1024 ? g : 1024), dim3(256), 0, st, n, r, colsum, x, b, (unsigned long long*)norms);
+}
+
 // relative map of every scatter problem: one workgroup per problem, lanes stride over its M source rows
 __global__ void __launch_bounds__(256)
 k_build_relmaps(const GemmProb* __restrict__ probs, const int32_t* __restrict__ Lsi, int32_t* __restrict__ RelMap) {

@@ -134,6 +134,7 @@ struct sf_chol_plan {
     // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
     sf::SolveTask* d_solve = nullptr;
     double* d_x = nullptr;
+    double* d_resid = nullptr;  // sf_chol_plan_validate: r | column sums | b | 4 norms
     struct SolveStep { int64_t fwd_first, bwd_first; int count; int big; int nrows_tasks; int small; int ndiag; };   // both launches of a step have `count` tasks; big: a panel of the step is wider than 64 columns
     int* d_solve_sync = nullptr;
     bool solve_bwd_fused = false;

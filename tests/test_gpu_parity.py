@@ -505,3 +505,53 @@ def test_two_matrix_threads_share_one_handler_list(oracle):
         t.join()
     common.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("case", ["chol2d", "chol3d", "lu_unsym", "lu_sym", "lu_pivoted"])
+def test_device_validate_matches_host_residual(oracle, case):
+    """sf_chol_plan_validate (b_i = 1 + i/n, device solve, residual kernels over the plan's copy of A) against the host
+    statements of the reference's validate() (C:3182-3263 / L:3702-3858): numpy on the same x, and the oracle's own
+    residual of the downloaded factor"""
+    import scipy.sparse as sp
+    lu = case.startswith("lu")
+    if case == "chol2d":
+        n, Cp, Ci, Cx = gen.laplacian_lower(48, 48); perm = nd_perm_py(48, 48, 1)
+    elif case in ("chol3d", "lu_sym"):
+        n, Cp, Ci, Cx = gen.laplacian_lower(12, 12, 12); perm = nd_perm_py(12, 12, 12)
+    elif case == "lu_unsym":
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(11, 11, 11, seed=3); perm = nd_perm_py(11, 11, 11)
+    else:
+        n, Cp, Ci, Cx = gen.unsymmetric_general(10, 10, 10, seed=21); perm = nd_perm_py(10, 10, 10)
+    if lu:
+        sym = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", case == "lu_sym")
+        plan = sf.LUPlan(sym)
+        plan.set_values(sym.Lx, None if case == "lu_sym" else sym.Ux)
+        if case == "lu_pivoted":
+            plan.set_pivoting(1.0)
+    else:
+        sym = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
+        plan = sf.CholPlan(sym)
+        plan.set_values(sym.Lx)
+    plan.factorize()
+    res, x = plan.validate(return_x=True)
+    b = 1.0 + np.arange(n) / n
+    x2 = plan.solve(b)                                    # two runs of one solve differ by the order of its fp64 atomics
+    assert np.max(np.abs(x - x2)) <= 1e-12 * np.max(np.abs(x2))
+    # the matrix the factorization works on, from the analysis
+    lc = np.repeat(np.arange(n), np.diff(sym.Lp))
+    A = sp.coo_matrix((sym.Lx, (sym.Li, lc)), shape=(n, n)).tocsr()
+    if lu and case != "lu_sym":
+        ur = np.repeat(np.arange(n), np.diff(sym.Up))
+        off = sym.Ui != ur
+        A = A + sp.coo_matrix((sym.Ux[off], (ur[off], sym.Ui[off])), shape=(n, n)).tocsr()
+    else:
+        off = sym.Li != lc
+        A = A + sp.coo_matrix((sym.Lx[off], (lc[off], sym.Li[off])), shape=(n, n)).tocsr()
+    r = A @ x - b
+    ref = float(np.abs(r).max() / (abs(A).sum(axis=0).max() * np.abs(x).max() + np.abs(b).max()))
+    assert res <= (1e-10 if case == "lu_pivoted" else 1e-13)
+    eps = np.finfo(np.float64).eps
+    assert abs(res - ref) <= 16 * eps                    # same formula; only the summation order inside r differs
+    if not lu:
+        assert abs(sf.validate_solution(sym, x) - ref) <= 16 * eps
+    plan.close()
