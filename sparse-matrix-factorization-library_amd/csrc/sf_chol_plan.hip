@@ -468,7 +468,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         // Schur updates of every supernode of this level into its ancestors
         const int64_t g0 = (int64_t)gtasks.size(), s0 = (int64_t)stasks.size();
         double level_small_flops = 0;
-        for (sf_long s : Sl) {
+        // longest K first: the tiles are claimed in list order (k_gemm's dynamic rounds), so the launch ends on its short tiles
+        std::vector<sf_long> Su(Sl.begin(), Sl.end());
+        std::stable_sort(Su.begin(), Su.end(), [&](sf_long a, sf_long b) { return Super[a + 1] - Super[a] > Super[b + 1] - Super[b]; });
+        for (sf_long s : Su) {
             const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
             const sf_long* rows = Lsi + Lsip[s];
             const double nk = nscol;
@@ -790,6 +793,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 p->bytes_device += ub;
             }
         }
+        // GEMM launches: 8 claim counters each (one per XCD) for the dynamic deal of their whole-tile rounds
+        for (Launch& L : p->launches)
+            if (L.kind == 2 || L.kind == 3 || L.kind == 4) { L.ticket = p->n_tickets; p->n_tickets += 8; }
+        if (const char* env = getenv("SF_GEMM_DYNAMIC")) p->gemm_dynamic = atoi(env) != 0;
         // + 2 doubles: the GEMM stages row PAIRS with 16-byte loads and may touch 8 bytes past the last panel
         const size_t xb = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
@@ -1030,7 +1037,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                     u1 = (uint32_t)((uint64_t)L.units * (uint64_t)(L.share_idx + 1) / (uint64_t)L.share_cnt);
                 }
                 sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, u0, u1,
-                                L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, st);
+                                L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, p->gemm_dynamic ? p->d_info + 1 + L.ticket : nullptr, st);
                 break;
             }
         }

@@ -14,7 +14,10 @@ constexpr int GEMM_BN = 128;    // tile extent along cj (target columns)
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_WAVES = 8;     // waves per GEMM workgroup (2 along ci x GEMM_WAVES/2 along cj)
 constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
-constexpr int GEMM_GRID = 512;   // persistent GEMM grid: 2 workgroups per CU x 256 CUs
+#ifndef SF_GEMM_GRID
+#define SF_GEMM_GRID 512
+#endif
+constexpr int GEMM_GRID = SF_GEMM_GRID;   // persistent GEMM grid: 2 workgroups per CU x 256 CUs (the macro: experiment builds)
 constexpr int GEMM_SLICE = 1 << 30;  // K steps per task (a tile's K range could be cut into slices; measured: it does not pay)
 constexpr int SU_TM = 64, SU_TN = 32;   // tile of k_update_small (one wave): rows x columns
 constexpr int SV_B = 256;         // columns per step of the device solve (4 sub-blocks of NB, one per wave)
@@ -127,9 +130,10 @@ void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* fl
 void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi, int32_t* RelMap, hipStream_t st);
 
 // kt_prefix[0..ntasks]: running count of 16-deep K steps of the launch's tiles (kt_prefix[ntasks] = total units);
-// this call executes the units [u_lo, u_hi) of the launch
+// this call executes the units [u_lo, u_hi) of the launch.  ticket: 8 zeroed counters (one per XCD) for the dynamic deal of
+// the whole-tile rounds, or nullptr for the static deal
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-                 int mode, double* Lsx, const int32_t* RelMap, hipStream_t st);
+                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st);
 
 // Schur updates with K <= SU_MAXK: tasks are SU_TM x SU_TN tiles (GemmTask.tm / .tn in those units), one wave each
 void launch_update_small(const GemmProb* probs, const GemmTask* tasks, int ntasks, double* Lsx, const int32_t* RelMap, hipStream_t st);

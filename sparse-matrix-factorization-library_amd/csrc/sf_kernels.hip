@@ -759,11 +759,21 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
 }
 
+#ifdef SF_EXP_TIMING            // tools/experiments/gemm_overhead.sh: per-tile time stamps of every workgroup (s_memtime)
+__device__ unsigned long long* g_exp_stamps = nullptr;      // [workgroup][64 tiles][4]
+void exp_set_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_stamps), &p, sizeof(p)); }
+#define SF_STAMP(slot) do { if (tid == 0 && g_exp_stamps && exp_tile < 64) \
+        g_exp_stamps[((size_t)blockIdx.x * 64 + exp_tile) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SF_STAMP(slot) do { } while (0)
+#endif
+
 template <int MODE, bool DMA>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap) {
+       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap, int* __restrict__ ticket) {
+    __shared__ int s_claim;
     __shared__ __attribute__((aligned(16))) double Ys[2][GEMM_BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Xs[2][GEMM_BK][LDS_LD];
     __shared__ int32_t rowmap[GEMM_BM];
@@ -783,11 +793,10 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
     // share when the launch is split over the ranks of a sharded factorization -- the update is a sum, any split is valid)
     const uint32_t T = u_hi - u_lo;
     const uint32_t G = gridDim.x;
-    uint32_t share;
-    {
-        const uint32_t b = blockIdx.x, q = G >> 3, r = G & 7, x = b & 7;
-        share = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
+    const uint32_t xcd = blockIdx.x & 7;
+    const uint32_t xcd_n = (G >> 3) + (xcd < (G & 7) ? 1u : 0u);                              // workgroups of this XCD
+    const uint32_t xcd_base = xcd < (G & 7) ? xcd * ((G >> 3) + 1) : (G & 7) * ((G >> 3) + 1) + (xcd - (G & 7)) * (G >> 3);
+    const uint32_t share = xcd_base + (blockIdx.x >> 3);
     // Whole tiles are dealt out in ROUNDS: in round r workgroup `share` takes tile t0 + r G + share, so the 64 workgroups
     // of an XCD (consecutive shares) work on 64 CONSECUTIVE tiles -- one supertile -- at the same time and march through K
     // together: each operand slice is fetched into that XCD's L2 once per round and re-used by the 8 tiles of its
@@ -803,18 +812,44 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
     const uint32_t head_end = (R > 0) ? kt_prefix[t0] : u_hi;
     const uint32_t tail_beg = (R > 0) ? kt_prefix[t0 + R * (int)G] : u_hi;
 
-    for (int ph = 0; ph < R + 2; ++ph) {
+    // ticket != nullptr: the rounds are DYNAMIC -- the workgroups of an XCD claim the tiles of that XCD's slots (the same
+    // tiles as in the static deal, so a supertile still shares one L2) from the XCD's counter in the order they get free; tiles of
+    // different K (different source supernodes in one launch) no longer leave a workgroup idle while its neighbour works off a
+    // round of long ones.  Head and tail are split statically as before.
+    int ph = 0, rr = 0;
+#ifdef SF_EXP_TIMING
+    int exp_tile = 0;
+    // per workgroup, behind the tile stamps: shader-clock and constant 100 MHz stamps at its first and last instruction
+    if (tid == 0 && g_exp_stamps) {
+        g_exp_stamps[(size_t)gridDim.x * 256 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        g_exp_stamps[(size_t)gridDim.x * 256 + blockIdx.x * 4 + 1] = wall_clock64();
+    }
+#endif
+    for (;;) {
     uint32_t u, u_end;
     int ti;
-    if (ph >= 1 && ph <= R) {
-        ti = t0 + (ph - 1) * (int)G + (int)share;
+    SF_STAMP(0);
+    if (ph == 1) {
+        uint32_t slot = share;
+        if (ticket != nullptr && R > 0) {
+            if (tid == 0) s_claim = __hip_atomic_fetch_add(ticket + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();                     // the barrier that ends a tile separates this read from the next claim
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(s_claim);
+            rr = (int)(c / xcd_n);
+            slot = xcd_base + c % xcd_n;
+        }
+        if (rr >= R) { ph = 2; continue; }
+        ti = t0 + rr * (int)G + (int)slot;
+        ++rr;
         u = kt_prefix[ti];
         u_end = kt_prefix[ti + 1];
     } else {
         const uint32_t ra = (ph == 0) ? u_lo : tail_beg, rb = (ph == 0) ? head_end : u_hi;
-        if (rb <= ra) continue;
-        const uint32_t U = (rb - ra + G - 1) / G;
-        if (share * U >= rb - ra) continue;
+        const uint32_t U = (rb > ra) ? (rb - ra + G - 1) / G : 0;
+        if (rb <= ra || share * U >= rb - ra) {
+            if (ph == 0) { ph = 1; continue; }
+            break;
+        }
         u = ra + share * U;
         u_end = min(rb, u + U);
         ti = last_le_u32(kt_prefix, ntasks + 1, u);
@@ -914,6 +949,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         store_tile(0, kt0 * GEMM_BK);
         if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        SF_STAMP(1);
         load_tile((kt0 + 1) * GEMM_BK);
         int buf = 0;
         if (quad_active) {
@@ -947,6 +983,14 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
             }
         }
 
+        SF_STAMP(2);
+#ifdef SF_EXP_SKIP_EPILOGUE      // ablation for tools/experiments/gemm_overhead.sh: one store per lane keeps the accumulators live
+        if (quad_active) {
+            double v = 0.0;
+            for (int tm = 0; tm < TMN; ++tm) for (int tn = 0; tn < 4; ++tn) for (int r = 0; r < 4; ++r) v += acc[tm][tn][r];
+            if (v == 12345.678) Lsx[pb.c_off] = v;
+        }
+#else
         if (quad_active) {
             double* __restrict__ Cg = Lsx + pb.c_off;
             const int64_t ldc = pb.ldc;
@@ -976,10 +1020,25 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
                 }
             }
         }
-        // the next tile re-uses the LDS buffers and the relative maps
+#endif
+        // the next tile re-uses the LDS buffers and the relative maps.  (A barrier that orders LDS only -- s_waitcnt lgkmcnt(0) +
+        // s_barrier, letting the tile's atomics drain under the next claim -- measured neutral: 544.2 vs 543.1 ms at 128^3.)
         __syncthreads();
+        SF_STAMP(3);
+#ifdef SF_EXP_TIMING
+        ++exp_tile;
+        SF_STAMP(0);
+#endif
     }
+    if (ph == 2) break;
+    if (ph == 0) ph = 1;
     }   // phases
+#ifdef SF_EXP_TIMING
+    if (tid == 0 && g_exp_stamps) {
+        g_exp_stamps[(size_t)gridDim.x * 256 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+        g_exp_stamps[(size_t)gridDim.x * 256 + blockIdx.x * 4 + 3] = wall_clock64();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1612,7 +1671,7 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
 }
 
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-                 int mode, double* Lsx, const int32_t* RelMap, hipStream_t st) {
+                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st) {
     if (ntasks <= 0 || u_hi <= u_lo) return;
     const uint32_t units = u_hi - u_lo;
     const uint32_t grid = units < (uint32_t)GEMM_GRID ? units : (uint32_t)GEMM_GRID;
@@ -1622,15 +1681,15 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
     const bool dma = e ? atoi(e) != 0 : true;
     if (dma) {
         if (mode == 1)
-            hipLaunchKernelGGL((k_gemm<1, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+            hipLaunchKernelGGL((k_gemm<1, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
         else
-            hipLaunchKernelGGL((k_gemm<0, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+            hipLaunchKernelGGL((k_gemm<0, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
         return;
     }
     if (mode == 1)
-        hipLaunchKernelGGL((k_gemm<1, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+        hipLaunchKernelGGL((k_gemm<1, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
     else
-        hipLaunchKernelGGL((k_gemm<0, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap);
+        hipLaunchKernelGGL((k_gemm<0, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
 }
 
 }  // namespace sf

@@ -158,6 +158,7 @@ struct sf_chol_plan {
     double* d_Lsx = nullptr;
     int* d_info = nullptr;      // [0]: status bits of the running factorization; [1 ..]: task-claim counters of the k_step launches
     int n_tickets = 0;
+    bool gemm_dynamic = true;   // k_gemm: whole-tile rounds claimed from per-XCD counters (SF_GEMM_DYNAMIC=0: static deal)
 
     PotrfTask* d_potrf = nullptr;
     TrsmTask* d_trsm = nullptr;

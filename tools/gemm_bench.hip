@@ -10,6 +10,7 @@
 #include <algorithm>
 #include "sf_kernels.h"
 
+namespace sf { void exp_set_stamps(unsigned long long* p); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -55,14 +56,59 @@ int main(int argc, char** argv) {
     const double alg = (double)N * (N + 1) * K + 2.0 * (double)(M - N) * N * K;
     const double exec = (double)pre.back() * 128.0 * 128.0 * 2.0 * sf::GEMM_BK;
     float best = 1e30f;
+    int* dticket;                                   // 6th argument 0: static deal of the rounds (default: dynamic, as in the library)
+    CK(hipMalloc(&dticket, 8 * sizeof(int)));
+    const int dynamic = argc > 6 ? atoi(argv[6]) : 1;
     for (int r = 0; r < reps; ++r) {
+        CK(hipMemset(dticket, 0, 8 * sizeof(int)));
         CK(hipEventRecord(e0));
-        sf::launch_gemm(dp, dt, dpre, (int)tasks.size(), 0, pre.back(), 0, d, nullptr, 0);
+        sf::launch_gemm(dp, dt, dpre, (int)tasks.size(), 0, pre.back(), 0, d, nullptr, dynamic ? dticket : nullptr, 0);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (r > 0 || reps == 1) best = std::min(best, ms);
     }
+#ifdef SF_EXP_TIMING
+    {
+        // per-tile stamps of one more launch: [0] tile start (claim, task / problem fetch, first tile load), [1] main loop starts,
+        // [2] main loop done, [3] epilogue + closing barrier done
+        const int G = sf::GEMM_GRID;
+        unsigned long long* ds;
+        CK(hipMalloc(&ds, (size_t)G * 65 * 4 * 8));
+        CK(hipMemset(ds, 0, (size_t)G * 65 * 4 * 8));
+        sf::exp_set_stamps(ds);
+        CK(hipMemset(dticket, 0, 8 * sizeof(int)));
+        sf::launch_gemm(dp, dt, dpre, (int)tasks.size(), 0, pre.back(), 0, d, nullptr, dynamic ? dticket : nullptr, 0);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs((size_t)G * 65 * 4);
+        CK(hipMemcpy(hs.data(), ds, hs.size() * 8, hipMemcpyDeviceToHost));
+        double pro = 0, loop = 0, epi = 0; long cnt = 0;
+        unsigned long long tmin = ~0ull, tmax = 0, first_end_min = ~0ull, last_start_max = 0;
+        for (int g = 0; g < G; ++g) {
+            unsigned long long wg_end = 0;
+            for (int t = 0; t < 64; ++t) {
+                const unsigned long long* q = &hs[((size_t)g * 64 + t) * 4];
+                if (!q[3]) break;
+                pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]); ++cnt;
+                tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[3]); wg_end = q[3];
+            }
+            if (wg_end) { first_end_min = std::min(first_end_min, wg_end); last_start_max = std::max(last_start_max, wg_end); }
+        }
+        // per workgroup: busy ticks / real time, first start and last end on the chip-wide 100 MHz clock
+        unsigned long long r0 = ~0ull, r1 = 0, rs_max = 0, re_min = ~0ull; double rate = 0, busy = 0;
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long* w = &hs[(size_t)G * 256 + g * 4];
+            r0 = std::min(r0, w[1]); r1 = std::max(r1, w[3]); rs_max = std::max(rs_max, w[1]); re_min = std::min(re_min, w[3]);
+            rate += (double)(w[2] - w[0]) / (double)(w[3] - w[1]); busy += (double)(w[3] - w[1]);
+        }
+        printf("  workgroups: shader ticks per 100 MHz tick %.2f; first start .. last start %.1f us; first end .. last end %.1f us; "
+               "kernel %.1f us; mean workgroup life %.1f us\n", rate / G, (rs_max - r0) / 100.0, (r1 - re_min) / 100.0, (r1 - r0) / 100.0, busy / G / 100.0);
+        const double span = (double)(tmax - tmin);
+        printf("  stamps: %ld tiles, span %.0f ticks; per tile: prologue %.0f, main loop %.0f (%.1f per K step), epilogue %.0f ticks; "
+               "workgroups end between %.3f and 1.000 of the span; ticks per ms %.0f\n", cnt, span, pro / cnt, loop / cnt,
+               loop / cnt / ((K + 15) / 16), epi / cnt, (double)(first_end_min - tmin) / span, span / best);
+    }
+#endif
     printf("gemm<0> atomic=%d M=%d N=%d K=%d tiles=%zu  %.3f ms  algorithmic %.2f TFLOP/s  (tile-executed %.2f TFLOP/s)\n", force_atomic, M, N, K,
            tasks.size(), best, alg / best / 1e9, exec / best / 1e9);
     return 0;
