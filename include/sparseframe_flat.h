@@ -265,6 +265,8 @@ int sf_lu_plan_destroy(sf_lu_plan *plan);
  * NULL when U aliases L).  serial selects the handler (matrix threads spread over the devices). ---- */
 int sf_handlers_allocate(struct common_info_struct *common_info, struct gpu_info_struct **gpu_info_list_ptr);
 int sf_handlers_free(struct common_info_struct *common_info, struct gpu_info_struct **gpu_info_list_ptr);
+/* device plans built so far by the handlers of a list (a repeated sparsity pattern must not add to it) */
+int64_t sf_handlers_plan_builds(struct gpu_info_struct *gpu_info_list, int n_handlers);
 int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_info_struct *gpu_info_list, int lu, int serial,
                           sf_long n, sf_long nsuper, const sf_long *Super, const sf_long *SuperMap,
                           const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,

@@ -560,6 +560,10 @@ class CommonInfo:
         if dev_slot_size is not None:
             self.c.devSlotSize = dev_slot_size
 
+    def plan_builds(self):
+        """device plans the handlers have built so far (a repeated sparsity pattern must not add to it)"""
+        return int(lib.sf_handlers_plan_builds(self.gpu_list, self.c.numGPU))
+
     def close(self):
         if self.gpu_list:
             lib.SparseFrame_free_gpu(C.byref(self.c), C.byref(self.gpu_list))

@@ -79,6 +79,7 @@ struct MultiState {
     struct Entry { PlanKey key; std::vector<sf_chol_plan*> plans; uint64_t stamp; };
     std::vector<Entry> cache;
     uint64_t clock = 0;
+    uint64_t builds = 0;        // sets of per-rank plans built (cache misses)
     ~MultiState() {
         for (Entry& e : cache)
             for (sf_chol_plan* p : e.plans) sf_chol_plan_destroy(p);
@@ -91,6 +92,7 @@ struct HandlerState {
     struct Entry { PlanKey key; sf_chol_plan* plan; uint64_t stamp; };
     std::vector<Entry> cache;
     uint64_t clock = 0;
+    uint64_t builds = 0;                // plans built by this handler (cache misses)
     MultiState* multi = nullptr;        // handler 0 only
     ~HandlerState() {
         for (Entry& e : cache) sf_chol_plan_destroy(e.plan);
@@ -144,6 +146,7 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
         if (sf::subtree_partition(nsuper, Super, SuperMap, Lsip, Lsi, N, owner.data(), nullptr, nullptr, 1.0 / N + 0.25)) return SF_ERR_ARG;
         M.cache.push_back(MultiState::Entry{key, std::vector<sf_chol_plan*>(N, nullptr), ++M.clock});
         entry = &M.cache.back();
+        ++M.builds;
     }
     std::vector<int> rcs(N, SF_OK);
     std::vector<std::thread> th;
@@ -220,6 +223,20 @@ int sf_handlers_allocate(struct common_info_struct* common, struct gpu_info_stru
     return 0;
 }
 
+// number of device plans (sets of per-rank plans for a multi-handler factorization) the handlers of a list have built so far:
+// a repeated sparsity pattern must not add to it (tests; SF_TRACE prints the same per call)
+int64_t sf_handlers_plan_builds(struct gpu_info_struct* list, int n_handlers) {
+    int64_t total = 0;
+    if (!list) return 0;
+    for (int d = 0; d < n_handlers; ++d) {
+        if (!list[d].st) continue;
+        std::lock_guard<std::mutex> guard(list[d].st->mu);
+        total += (int64_t)list[d].st->builds;
+        if (list[d].st->multi) total += (int64_t)list[d].st->multi->builds;
+    }
+    return total;
+}
+
 int sf_handlers_free(struct common_info_struct* common, struct gpu_info_struct** list) {
     if (!list || !*list) return 1;
     const auto t0 = std::chrono::steady_clock::now();
@@ -291,6 +308,7 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
         }
         if (rc) return rc;
         S.cache.push_back(HandlerState::Entry{key, plan, ++S.clock});
+        ++S.builds;
     }
     const auto tk2 = std::chrono::steady_clock::now();
     int rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);

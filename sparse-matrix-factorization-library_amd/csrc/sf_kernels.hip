@@ -145,18 +145,20 @@ __device__ __forceinline__ double readlane_dyn_f64(double v, int l) {      // l 
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-template <bool RCP>
-__device__ __forceinline__ int getrf_wave(double (&a)[NB], int lane, int b, double tol, double eps, bool& bad, int& nperturbed) {
-    int pos = lane;
-    bool active = lane < b;
+// W columns J0 .. J0 + W - 1 of the block (a[u] = D(lane, J0 + u)); `active` / `pos` carry the state of the lanes across the panels
+// of a blocked factorization (k_step<true>), piv_rows[J] receives the row chosen at column J.  W = NB, J0 = 0 is the whole block.
+template <bool RCP, int W>
+__device__ __forceinline__ void getrf_panel_wave(double (&a)[W], int lane, int J0, int b, double tol, double eps, bool& bad, int& nperturbed,
+                                                 int& pos, bool& active, int* piv_rows) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        int p = j;
-        if (tol > 0.0 && j < b) {               // wave-uniform: no pivot search when pivoting is off or in the padding
+    for (int j = 0; j < W; ++j) {
+        const int J = J0 + j;
+        int p = J;
+        if (tol > 0.0 && J < b) {               // wave-uniform: no pivot search when pivoting is off or in the padding
             // cheap test first: an upper bound of max |a_ij| from ONE reduction over the high words; the exact arg-max (a second
             // reduction and a ballot) only when the natural row fails it
-            const double nat = readlane_f64(a[j], j);
-            const bool nat_free = ((__ballot(active) >> j) & 1ull) != 0;
+            const double nat = readlane_dyn_f64(a[j], J);
+            const bool nat_free = ((__ballot(active) >> J) & 1ull) != 0;
             const uint32_t mhi = wave_max_u32(active ? (((uint32_t)__double2hiint(a[j]) & 0x7fffffffu) + 1u) : 0u);
             const double m_ub = __hiloint2double((int)(mhi - 1u), -1);
             if (!(nat_free && mhi != 0u && fabs(nat) >= tol * m_ub && nat != 0.0)) {
@@ -167,7 +169,7 @@ __device__ __forceinline__ int getrf_wave(double (&a)[NB], int lane, int b, doub
             p = __builtin_amdgcn_readfirstlane(p);
         }
         double piv = readlane_dyn_f64(a[j], p);
-        if (j < b && eps > 0.0 && !(fabs(piv) >= eps) && piv == piv) {      // tiny (or zero) pivot: perturb
+        if (J < b && eps > 0.0 && !(fabs(piv) >= eps) && piv == piv) {      // tiny (or zero) pivot: perturb
             piv = (piv < 0.0) ? -eps : eps;
             ++nperturbed;
             if (lane == p) a[j] = piv;
@@ -184,10 +186,18 @@ __device__ __forceinline__ int getrf_wave(double (&a)[NB], int lane, int b, doub
             l = elim ? a[j] / piv : 0.0;
         }
         if (elim) a[j] = l;
-        if (lane == p) { pos = j; active = false; }
+        if (lane == p) { pos = J; active = false; }
+        if (piv_rows != nullptr && lane == 0) piv_rows[J] = p;
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) a[c] -= l * readlane_dyn_f64(a[c], p);
+        for (int c = j + 1; c < W; ++c) a[c] -= l * readlane_dyn_f64(a[c], p);
     }
+}
+
+template <bool RCP>
+__device__ __forceinline__ int getrf_wave(double (&a)[NB], int lane, int b, double tol, double eps, bool& bad, int& nperturbed) {
+    int pos = lane;
+    bool active = lane < b;
+    getrf_panel_wave<RCP, NB>(a, lane, 0, b, tol, eps, bad, nperturbed, pos, active, nullptr);
     return pos;
 }
 
@@ -1202,32 +1212,101 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     }
 
     if (LU && is_diag) {
+        // LU of the updated block with threshold pivoting inside it (pc.tol > 0; implicit interchanges: rows stay where they are
+        // until the final store), BLOCKED by 16 columns like the Cholesky path below:
+        //   panel    wave 0, lane r holds the 16 panel entries of row r: getrf_panel_wave (pivot search over the rows not used yet,
+        //            v_readlane broadcasts of the pivot row, multipliers by v_rcp_f64 + two Newton steps);
+        //   U12      the 16 pivot rows of the panel in the columns to its right: one thread per column, forward substitution
+        //            with the panel's multipliers (LDS broadcasts);
+        //   trailing every wave its 16 rows x the columns to the right with MFMA out of LDS, the multipliers of rows that are
+        //            already used (in this or an earlier panel) masked to zero, the U12 rows gathered through the pivot list.
+        // The unblocked form (getrf_wave: a 64-value row per lane, 4,000 v_readlane pairs on the critical path) cost 68 us per
+        // step and 256 VGPRs; see DESIGN 6b for the figures of this one.
+        __shared__ int s_piv[NB], s_pos[NB];
+        if (tid < NB) s_pos[tid] = -1;
         __syncthreads();
-        if (wave == 0) {
-        // LU of the updated block (getrf_wave: lane r holds row r; threshold pivoting inside the block when pc.tol > 0, implicit
-        // interchanges), multipliers with the reciprocal from v_rcp_f64 + two Newton steps (the IEEE divide sequence sits on the
-        // 64-step critical path).  Rows are stored at their pivot positions.
-        double a[NB];
+        bool bad = false, active = lane < b;
+        int np = 0, pos = lane;
+#pragma unroll 1
+        for (int q = 0; q < NB / 16; ++q) {
+            const int c0 = 16 * q;
+            if (wave == 0) {
+                double a[16];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = U[c * ST_ULD + lane];
-        bool bad = false;
-        int np = 0;
-        const int pos = getrf_wave<true>(a, lane, b, pc.tol, pc.eps, bad, np);
-        if (bad && lane == 0) atomicOr(info, 1);
-        if (np > 0 && lane == 0) atomicAdd(pc.nperturb, np);
-        double* __restrict__ PUd = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
+                for (int u = 0; u < 16; ++u) a[u] = U[(c0 + u) * ST_ULD + lane];
+                getrf_panel_wave<true, 16>(a, lane, c0, b, pc.tol, pc.eps, bad, np, pos, active, s_piv);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            if (lane < b && c < b) {
-                if (c < pos) Ag[pos + (int64_t)c * ld] = a[c]; else PUd[c + (int64_t)pos * ld] = a[c];
+                for (int u = 0; u < 16; ++u) U[(c0 + u) * ST_ULD + lane] = a[u];
+                s_pos[lane] = active ? -1 : pos;
             }
-            U[c * ST_ULD + pos] = a[c];         // the factored block (L below, U on and above the diagonal; identity padding)
+            if (q == NB / 16 - 1 || c0 + 16 >= b) break;      // nothing but identity padding to the right (narrow panel)
+            __syncthreads();
+            const int ntr = NB - c0 - 16;               // columns to the right of the panel
+            if (tid < ntr) {
+                const int c = c0 + 16 + tid;
+                double x[16];
+                int pr[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { pr[k] = s_piv[c0 + k]; x[k] = U[c * ST_ULD + pr[k]]; }
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+#pragma unroll
+                    for (int jj = 0; jj < k; ++jj) x[k] -= U[(c0 + jj) * ST_ULD + pr[k]] * x[jj];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) U[c * ST_ULD + pr[k]] = x[k];
+            }
+            __syncthreads();
+            {
+                const int ci = 16 * wave + fr;          // this wave's 16 rows
+                const bool free_row = s_pos[ci] < 0;
+                double lf[4];
+                int pk[4];
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    const double v = U[(c0 + 4 * sgm + fk) * ST_ULD + ci];
+                    lf[sgm] = free_row ? v : 0.0;                                                   // B[k][j = ci]
+                    pk[sgm] = s_piv[c0 + 4 * sgm + fk];
+                }
+                for (int ct = q + 1; ct < NB / 16; ++ct) {
+                    const int cb = 16 * ct;
+                    double4_t d;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[r] = U[(cb + fk + 4 * r) * ST_ULD + ci];          // D[i = column][j = row ci]
+#pragma unroll
+                    for (int sgm = 0; sgm < 4; ++sgm)
+                        d = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(cb + fr) * ST_ULD + pk[sgm]], lf[sgm], d, 0, 0, 0);   // A[i][k] = U12(k, cb + i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) U[(cb + fk + 4 * r) * ST_ULD + ci] = d[r];
+                }
+            }
+            __syncthreads();
         }
-        if (pc.pivpos && lane < b) {
-            const int g0 = t.first_col + t.diag;
-            pc.pivpos[g0 + lane] = g0 + pos;
-            pc.pivinv[g0 + pos] = g0 + lane;
+        if (wave == 0) {
+            if (bad && lane == 0) atomicOr(info, 1);
+            if (np > 0 && lane == 0) atomicAdd(pc.nperturb, np);
+            if (pc.pivpos && lane < b) {
+                const int g0 = t.first_col + t.diag;
+                pc.pivpos[g0 + lane] = g0 + pos;
+                pc.pivinv[g0 + pos] = g0 + lane;
+            }
         }
+        __syncthreads();
+        {
+            // rows go to their pivot positions: wave w moves the columns 16 w .. 16 w + 15 (its reads precede its writes, and no
+            // other wave touches these columns), L part to the L panel, U part (transposed) to the U^T panel
+            const int mypos = s_pos[lane];
+            double* __restrict__ PUd = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
+            double a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = U[(16 * wave + u) * ST_ULD + lane];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = 16 * wave + u;
+                if (lane < b && c < b) {
+                    if (c < mypos) Ag[mypos + (int64_t)c * ld] = a[u]; else PUd[c + (int64_t)mypos * ld] = a[u];
+                }
+                U[c * ST_ULD + mypos] = a[u];       // the factored block (L below, U on and above the diagonal; identity padding)
+            }
         }
         __syncthreads();
         {

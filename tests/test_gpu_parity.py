@@ -432,14 +432,14 @@ def test_struct_entry_point_reuses_cached_plan(oracle):
     sym = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
     ref, info, _ = oracle.chol_factorize(sym)
     mask = oracle.lower_mask(sym)
-    times = []
+    builds = []
     for scale in (1.0, 4.0, 9.0):
         mi = sf.MatrixInfo()
         mi.set_csc(n, Cp, Ci, Cx * scale)
         mi.set_perm(perm)
         mi.analyze(common)
         mi.factorize(common)
-        times.append(mi.c.factorizeTime)
+        builds.append(common.plan_builds())
         assert rel_err(mi.array("Lsx", sym.xsize).copy(), ref * np.sqrt(scale), mask) <= TOL_FACTOR
         assert mi.validate() <= TOL_RESIDUAL
         mi.cleanup()
@@ -450,8 +450,8 @@ def test_struct_entry_point_reuses_cached_plan(oracle):
     mi.factorize(common)
     assert mi.validate() <= TOL_RESIDUAL
     mi.cleanup()
+    assert builds == [1, 1, 1] and common.plan_builds() == 2    # one plan per pattern, however often it is factorized
     common.close()
-    assert times[1] < times[0] and times[2] < times[0]          # the plan was built once
 
 
 def test_gemm_register_staged_form(oracle, monkeypatch):
