@@ -27,8 +27,8 @@ double wall_seconds() {
     return tp.tv_sec + (double)tp.tv_nsec / 1.0e9;
 }
 
-template <class T>
-T* dup_array(const std::vector<T>& v, size_t min_elems = 1) {
+template <class T, class A>
+T* dup_array(const std::vector<T, A>& v, size_t min_elems = 1) {
     const size_t n = v.size() > min_elems ? v.size() : min_elems;
     T* p = (T*)malloc(n * sizeof(T));
     if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
@@ -113,6 +113,11 @@ const sf_long* sf_symbolic_long_array(const sf_symbolic* sym, const char* name, 
     const sf::Symbolic& S = sym->S;
     const std::string k(name);
     const std::vector<Long>* v = nullptr;
+    const sf::RawVec<Long>* w = (k == "Li") ? &S.Li : (k == "LTi") ? &S.LTi : (k == "Ui") ? &S.Ui : (k == "UTi") ? &S.UTi : nullptr;
+    if (w) {
+        if (len) *len = (sf_long)w->size();
+        return (const sf_long*)w->data();
+    }
     if (k == "Perm") v = &S.Perm;
     else if (k == "Parent") v = &S.Parent;
     else if (k == "Parent0") v = &S.Parent0;
@@ -120,13 +125,9 @@ const sf_long* sf_symbolic_long_array(const sf_symbolic* sym, const char* name, 
     else if (k == "ColCount") v = &S.ColCount;
     else if (k == "ColCount0") v = &S.ColCount0;
     else if (k == "Lp") v = &S.Lp;
-    else if (k == "Li") v = &S.Li;
     else if (k == "LTp") v = &S.LTp;
-    else if (k == "LTi") v = &S.LTi;
     else if (k == "Up") v = &S.Up;
-    else if (k == "Ui") v = &S.Ui;
     else if (k == "UTp") v = &S.UTp;
-    else if (k == "UTi") v = &S.UTi;
     else if (k == "Super") v = &S.Super;
     else if (k == "SuperMap") v = &S.SuperMap;
     else if (k == "Sparent") v = &S.Sparent;
@@ -148,7 +149,7 @@ const sf_float* sf_symbolic_float_array(const sf_symbolic* sym, const char* name
     if (len) *len = 0;
     if (!sym || !name) return nullptr;
     const std::string k(name);
-    const std::vector<double>* v = nullptr;
+    const sf::RawVec<double>* v = nullptr;
     if (k == "Lx") v = &sym->S.Lx;
     else if (k == "LTx") v = &sym->S.LTx;
     else if (k == "Ux") v = &sym->S.Ux;

@@ -33,98 +33,114 @@ bool relax_allowed(Long ncol, double zero_rate) {
     return true;
 }
 
+// host threads of the analysis (the bucket sorts below; SF_ANALYZE_THREADS overrides, 1 = the sequential code path of round 1)
+int analysis_threads() {
+    static const int T = [] {
+        if (const char* e = getenv("SF_ANALYZE_THREADS")) return std::max(1, atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(hc ? hc : 1u, 8u);
+    }();
+    return T;
+}
+
+template <class F>
+void parallel_ranges(int T, Long n, F&& body) {      // body(t, begin, end) on T host threads over [0, n)
+    if (T <= 1 || n < ((Long)1 << 15)) { body(0, (Long)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { body(t, n * t / T, n * (t + 1) / T); });
+    body(0, (Long)0, n / T);
+    for (auto& x : th) x.join();
+}
+
+// The entry stream of P A P^T in the traversal order of C:1036-1063 (new column j = 0 .. n-1, the entries of the original column
+// Perm[j] in their stored order): e -> (row i, column j, value) in the NEW numbering.  Built once, in parallel over column ranges;
+// every triangle below is a stable bucket sort of it.
+struct EntryStream {
+    RawVec<Long> row, col;
+    RawVec<double> val;
+    Long E = 0;
+};
+void build_stream(Long n, const Long* Cp, const Long* Ci, const double* Cx, const std::vector<Long>& Perm, EntryStream& st) {
+    std::vector<Long> Pinv(n, -1);
+    for (Long j = 0; j < n; ++j)
+        if (Perm[j] >= 0) Pinv[Perm[j]] = j;
+    std::vector<Long> off(n + 1, 0);
+    for (Long j = 0; j < n; ++j) off[j + 1] = off[j] + (Perm[j] >= 0 ? Cp[Perm[j] + 1] - Cp[Perm[j]] : 0);
+    st.E = off[n];
+    st.row.resize(st.E); st.col.resize(st.E); st.val.resize(st.E);
+    parallel_ranges(analysis_threads(), n, [&](int, Long j0, Long j1) {
+        for (Long j = j0; j < j1; ++j) {
+            const Long jold = Perm[j];
+            if (jold < 0) continue;
+            Long e = off[j];
+            for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p, ++e) {
+                st.row[e] = Pinv[Ci[p]];
+                st.col[e] = j;
+                st.val[e] = Cx ? Cx[p] : 0.0;
+            }
+        }
+    });
+}
+
+// Stable bucket sort of the stream: entry e goes to bucket key(e) (-1: not in this part) carrying idx(e) and its value; inside a
+// bucket the entries keep the stream order (= the sequential fill of C:1036-1063).  Thread t owns the buckets [n t/T, n (t+1)/T): it
+// scans the whole key stream (sequential reads) and handles the keys of its range -- no atomics, no per-thread histograms, and its
+// scattered writes stay inside its own slice of the output.
+template <class K, class Ix>
+void bucket_stream(Long n, const EntryStream& st, int T, K&& key, Ix&& idx, std::vector<Long>& P, RawVec<Long>& I, RawVec<double>& X) {
+    P.assign(n + 1, 0);
+    parallel_ranges(T, n, [&](int, Long b0, Long b1) {
+        for (Long e = 0; e < st.E; ++e) {
+            const Long k = key(e);
+            if (k >= b0 && k < b1) P[k + 1]++;
+        }
+    });
+    for (Long j = 0; j < n; ++j) P[j + 1] += P[j];
+    I.resize(P[n]); X.resize(P[n]);
+    parallel_ranges(T, n, [&](int, Long b0, Long b1) {
+        std::vector<Long> next(P.begin() + b0, P.begin() + b1);
+        for (Long e = 0; e < st.E; ++e) {
+            const Long k = key(e);
+            if (k >= b0 && k < b1) {
+                const Long q = next[k - b0]++;
+                I[q] = idx(e);
+                X[q] = st.val[e];
+            }
+        }
+    });
+}
+
 // lower(P A P^T) by column (column = min(i,j), row = max(i,j)) and its transpose.
 // Entry order inside a column follows the traversal order of C:1036-1063.
 // LU with an unsymmetric input (L:1179-1282): entry (i,j) of P A P^T goes to L (by column j, rows i >= j) when
 // j <= i and to U (by ROW i, columns j >= i) when j >= i; the diagonal is in both.
-void build_lu_parts(Long n, const Long* Cp, const Long* Ci, const double* Cx,
-                    const std::vector<Long>& Perm, Symbolic& S) {
-    std::vector<Long> Pinv(n, -1);
-    for (Long j = 0; j < n; ++j)
-        if (Perm[j] >= 0) Pinv[Perm[j]] = j;
-    S.Lp.assign(n + 1, 0); S.LTp.assign(n + 1, 0); S.Up.assign(n + 1, 0); S.UTp.assign(n + 1, 0);
-    for (Long j = 0; j < n; ++j) {
-        const Long jold = Perm[j];
-        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
-            const Long i = Pinv[Ci[p]];
-            if (j <= i) { S.Lp[j + 1]++; S.LTp[i + 1]++; }
-            if (j >= i) { S.Up[i + 1]++; S.UTp[j + 1]++; }
-        }
-    }
-    for (Long j = 0; j < n; ++j) {
-        S.Lp[j + 1] += S.Lp[j]; S.LTp[j + 1] += S.LTp[j];
-        S.Up[j + 1] += S.Up[j]; S.UTp[j + 1] += S.UTp[j];
-    }
-    S.Li.resize(S.Lp[n]); S.Lx.resize(S.Lp[n]); S.LTi.resize(S.Lp[n]); S.LTx.resize(S.Lp[n]);
-    S.Ui.resize(S.Up[n]); S.Ux.resize(S.Up[n]); S.UTi.resize(S.Up[n]); S.UTx.resize(S.Up[n]);
-    std::vector<Long> ln(S.Lp.begin(), S.Lp.end() - 1), ltn(S.LTp.begin(), S.LTp.end() - 1);
-    std::vector<Long> un(S.Up.begin(), S.Up.end() - 1), utn(S.UTp.begin(), S.UTp.end() - 1);
-    for (Long j = 0; j < n; ++j) {
-        const Long jold = Perm[j];
-        for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
-            const Long i = Pinv[Ci[p]];
-            const double v = Cx ? Cx[p] : 0.0;
-            if (j <= i) {
-                const Long lp = ln[j]++;  S.Li[lp] = i;  S.Lx[lp] = v;
-                const Long tp = ltn[i]++; S.LTi[tp] = j; S.LTx[tp] = v;
-            }
-            if (j >= i) {
-                const Long up = un[i]++;  S.Ui[up] = j;  S.Ux[up] = v;
-                const Long tp = utn[j]++; S.UTi[tp] = i; S.UTx[tp] = v;
-            }
-        }
-    }
+void build_lu_parts(Long n, const EntryStream& st, Symbolic& S) {
+    const int T = std::max(1, analysis_threads() / 4);
+    const Long* R = st.row.data();
+    const Long* Cc = st.col.data();
+    std::thread t1([&] { bucket_stream(n, st, T, [=](Long e) { return Cc[e] <= R[e] ? R[e] : (Long)-1; }, [=](Long e) { return Cc[e]; }, S.LTp, S.LTi, S.LTx); });
+    std::thread t2([&] { bucket_stream(n, st, T, [=](Long e) { return Cc[e] >= R[e] ? R[e] : (Long)-1; }, [=](Long e) { return Cc[e]; }, S.Up, S.Ui, S.Ux); });
+    std::thread t3([&] { bucket_stream(n, st, T, [=](Long e) { return Cc[e] >= R[e] ? Cc[e] : (Long)-1; }, [=](Long e) { return R[e]; }, S.UTp, S.UTi, S.UTx); });
+    bucket_stream(n, st, T, [=](Long e) { return Cc[e] <= R[e] ? Cc[e] : (Long)-1; }, [=](Long e) { return R[e]; }, S.Lp, S.Li, S.Lx);
+    t1.join(); t2.join(); t3.join();
 }
 
 void build_triangles(Long n, const Long* Cp, const Long* Ci, const double* Cx,
                      const std::vector<Long>& Perm, Symbolic& S) {
-    if (S.lu && !S.symmetric) { build_lu_parts(n, Cp, Ci, Cx, Perm, S); return; }
-    std::vector<Long> Pinv(n, -1);
-    for (Long j = 0; j < n; ++j)
-        if (Perm[j] >= 0) Pinv[Perm[j]] = j;
-
-    const Long nz = Cp[n];
-    S.Lp.assign(n + 1, 0);
-    S.LTp.assign(n + 1, 0);
-    S.Li.resize(nz);  S.Lx.resize(nz);
-    S.LTi.resize(nz); S.LTx.resize(nz);
-
-    // L (by column) and L^T (by row) are two independent bucket sorts of the same entry stream, each filled in the traversal
-    // order of C:1036-1063: one host thread each (the scattered writes are latency-bound, the two do not share a cache line)
-    auto build = [&](bool transpose) {
-        std::vector<Long>& P = transpose ? S.LTp : S.Lp;
-        std::vector<Long>& I = transpose ? S.LTi : S.Li;
-        std::vector<double>& X = transpose ? S.LTx : S.Lx;
-        for (Long j = 0; j < n; ++j) {
-            const Long jold = Perm[j];
-            if (jold < 0) continue;
-            for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
-                const Long i = Pinv[Ci[p]];
-                P[(transpose ? std::max(i, j) : std::min(i, j)) + 1]++;
-            }
-        }
-        for (Long j = 0; j < n; ++j) P[j + 1] += P[j];
-        std::vector<Long> next(P.begin(), P.end() - 1);
-        for (Long j = 0; j < n; ++j) {
-            const Long jold = Perm[j];
-            if (jold < 0) continue;
-            for (Long p = Cp[jold]; p < Cp[jold + 1]; ++p) {
-                const Long i = Pinv[Ci[p]];
-                const Long lo = std::min(i, j), hi = std::max(i, j);
-                const Long q = next[transpose ? hi : lo]++;
-                I[q] = transpose ? lo : hi;
-                X[q] = Cx ? Cx[p] : 0.0;
-            }
-        }
-    };
-    if (nz > (Long)1 << 16) {
-        std::thread t(build, true);
-        build(false);
-        t.join();
-    } else {
-        build(false);
-        build(true);
-    }
+    EntryStream st;
+    const bool tr_ = getenv("SF_TRACE") != nullptr;
+    auto now_ = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec / 1e6; };
+    const double t0_ = now_();
+    build_stream(n, Cp, Ci, Cx, Perm, st);
+    if (tr_) fprintf(stderr, "[sparseframe-hip]   entry stream %.1f ms (%d threads)\n", now_() - t0_, analysis_threads());
+    if (S.lu && !S.symmetric) { build_lu_parts(n, st, S); return; }
+    // L (by column) and L^T (by row) are two independent stable bucket sorts of the same stream
+    const int T = std::max(1, analysis_threads() / 2);
+    const Long* R = st.row.data();
+    const Long* Cc = st.col.data();
+    std::thread t([&] { bucket_stream(n, st, T, [=](Long e) { return std::max(R[e], Cc[e]); }, [=](Long e) { return std::min(R[e], Cc[e]); }, S.LTp, S.LTi, S.LTx); });
+    bucket_stream(n, st, T, [=](Long e) { return std::min(R[e], Cc[e]); }, [=](Long e) { return std::max(R[e], Cc[e]); }, S.Lp, S.Li, S.Lx);
+    t.join();
 }
 
 // Liu's elimination tree with path compression over the rows of L (columns of L^T).
@@ -414,7 +430,7 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
         for (Long j = 0; j < n; ++j) {
             for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
                 const std::vector<Long>& Tp = pass ? S.UTp : S.LTp;
-                const std::vector<Long>& Ti = pass ? S.UTi : S.LTi;
+                const RawVec<Long>& Ti = pass ? S.UTi : S.LTi;
                 for (Long p = Tp[j]; p < Tp[j + 1]; ++p) {
                     for (Long d = S.SuperMap[Ti[p]]; d >= 0 && Marker[d] <= j; d = S.Sparent[d]) {
                         if (fill[d] >= S.Lsip[d + 1]) return 2;  // count mismatch: symbolic inconsistency

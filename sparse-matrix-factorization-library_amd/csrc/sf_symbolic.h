@@ -2,11 +2,24 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace sf {
 
 using Long = int64_t;
+
+// std::vector whose resize() leaves new elements uninitialized: the index / value arrays of the triangles are tens to hundreds of
+// MB that are overwritten entry by entry right after; zero-filling them first is a single-threaded pass over fresh pages
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using RawVec = std::vector<T, default_init_allocator<T>>;
 
 struct Symbolic {
     Long n = 0;
@@ -16,11 +29,13 @@ struct Symbolic {
     bool symmetric = true;   // input holds one triangle of a symmetric matrix (LU: U aliases L, L:2718-2729)
 
     // permuted lower triangle (by column) and its transpose; reference C:956-1066
-    std::vector<Long> Lp, Li, LTp, LTi;
-    std::vector<double> Lx, LTx;
+    std::vector<Long> Lp, LTp;
+    RawVec<Long> Li, LTi;
+    RawVec<double> Lx, LTx;
     // LU, unsymmetric input only: U by ROW (Up[i]..: column indices j >= i) and its transpose (L:1179-1282)
-    std::vector<Long> Up, Ui, UTp, UTi;
-    std::vector<double> Ux, UTx;
+    std::vector<Long> Up, UTp;
+    RawVec<Long> Ui, UTi;
+    RawVec<double> Ux, UTx;
 
     std::vector<Long> Perm;      // final (post-order composed), C:1438
     std::vector<Long> Parent;    // final numbering, C:1439
