@@ -70,6 +70,12 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->ev_s0) (void)hipEventDestroy(p->ev_s0);
     if (p->ev_s1) (void)hipEventDestroy(p->ev_s1);
+    for (int k = 0; k < 2; ++k) {
+        if (p->ev_contrib[k]) (void)hipEventDestroy(p->ev_contrib[k]);
+        if (p->ev_reduced[k]) (void)hipEventDestroy(p->ev_reduced[k]);
+        if (p->ev_unpacked[k]) (void)hipEventDestroy(p->ev_unpacked[k]);
+    }
+    if (p->stream2) (void)hipStreamDestroy(p->stream2);
     for (hipEvent_t e : p->dl_events)
         if (e) (void)hipEventDestroy(e);
     for (int w = 0; w < DL_WORKERS_MAX; ++w) {
@@ -241,11 +247,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // slicing 556 ms; slices of 512 / 256 / 128 steps 563 / 569 / 569 ms -- every extra slice is one more atomic pass over
     // the target tile, which costs more than the extra rounds gain.  GEMM_SLICE is therefore "never" (one slice).
     const int gemm_slice = sf::GEMM_SLICE;
-    auto add_tiles = [&](int32_t prob_id, int M, int N, int K) {
+    // kt_lo / kt_hi: the K steps [kt_lo, kt_hi) of the problem only (look-ahead: the far part and the last block's part of an outer
+    // GEMM are separate launches); default = all of K
+    auto add_tiles = [&](int32_t prob_id, int M, int N, int K, int kt_lo = 0, int kt_hi = -1) {
         const int tmn = (M + sf::GEMM_BM - 1) / sf::GEMM_BM, tnn = (N + sf::GEMM_BN - 1) / sf::GEMM_BN;
         const int sw = std::min(tnn, 8), sh = std::max(1, 64 / sw);
-        const int nkt_all = (K + sf::GEMM_BK - 1) / sf::GEMM_BK;
-        for (int k0 = 0; k0 < nkt_all; k0 += gemm_slice)
+        const int nkt_all = kt_hi >= 0 ? kt_hi : (K + sf::GEMM_BK - 1) / sf::GEMM_BK;
+        for (int k0 = kt_lo; k0 < nkt_all; k0 += gemm_slice)
         for (int sj = 0; sj < tnn; sj += sw)
             for (int si = 0; si < tmn; si += sh)
                 for (int tn = sj; tn < std::min(sj + sw, tnn); ++tn)
@@ -274,6 +282,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // stay covered by the tests
     int64_t fuse_max = 32 * sf::GEMM_GRID;
     if (const char* env = getenv("SF_FUSE_MAX")) fuse_max = strtoll(env, nullptr, 10);
+    if (const char* env = getenv("SF_LOOKAHEAD")) p->lookahead = atoi(env) != 0;      // 0: the round-1 schedule (tests cover both)
     // The sweep: one set of independent supernodes at a time -- phase 0: a level of the owned subtrees; phase 1: the top
     // supernodes of one level that share one group of ranks (ascending mask: every rank meets the sets it shares with
     // another rank in the same order, so the groups' collectives cannot wait for each other in a circle).
@@ -314,36 +323,46 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         // The K = NB updates are HBM-bound read-modify-writes; confining them to OUTER_NB columns cuts
         // their traffic by n / OUTER_NB, the rest of the flops run at large K out of LDS/registers.
         const int nouter = (int)((maxcol + sf::OUTER_NB - 1) / sf::OUTER_NB);
-        for (int jo = 0; jo < nouter; ++jo) {
-            const int J = jo * sf::OUTER_NB;
-            if (jo > 0) {
-                const int64_t g0 = (int64_t)gtasks.size();
-                for (sf_long s : Sl) {
-                    const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
-                    if (J >= nscol) continue;
-                    GemmProb g{};
-                    g.lda = nsrow; g.ldc = nsrow;
-                    g.M = nsrow - J; g.N = std::min(sf::OUTER_NB, nscol - J); g.K = J;
-                    const int64_t src = XP[s] + J;                    // rows J.. , columns 0..J-1
-                    const int64_t dst = XP[s] + J + (int64_t)J * nsrow;
-                    const double fl = (double)g.N * (g.N + 1) * g.K + 2.0 * (g.M - g.N) * (double)g.N * g.K;
-                    for (int side = 0; side < (lu ? 2 : 1); ++side) {     // side 0: (L) panel, side 1: U^T panel
-                        g.y_off = src + (side ? ushift : 0);
-                        g.x_off = src + ((lu && !side) ? ushift : 0);
-                        g.c_off = dst + (side ? ushift : 0);
-                        g.strict = (lu && !side) ? 1 : 0;
-                        p->flops_outer_gemm += fl;
-                        p->flops_panel_gemm += fl;
-                        probs.push_back(g);
-                        add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K);
-                    }
-                }
-                if ((int64_t)gtasks.size() > g0) {
-                    p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
-                    p->launches.back().split = shared && LS.share_cnt > 1;
-                    p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
+        // The left-looking update of the outer block at column J2: K steps [kt_lo, kt_hi) of its K = J2 columns (all of them:
+        // kt_hi < 0), one launch for the panels of the set; `split`: shared among the ranks of the group (its result is part of a
+        // sum that is reduced later) or executed in full by every rank (its target has already been reduced)
+        auto outer_gemm = [&](int J2, int kt_lo, int kt_hi, bool split, bool count_flops) {
+            const int64_t g0 = (int64_t)gtasks.size();
+            for (sf_long s : Sl) {
+                const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                if (J2 >= nscol) continue;
+                GemmProb g{};
+                g.lda = nsrow; g.ldc = nsrow;
+                g.M = nsrow - J2; g.N = std::min(sf::OUTER_NB, nscol - J2); g.K = J2;
+                const int64_t src = XP[s] + J2;                    // rows J2.. , columns 0..J2-1
+                const int64_t dst = XP[s] + J2 + (int64_t)J2 * nsrow;
+                const double kk = (kt_hi < 0 ? g.K : (kt_hi - kt_lo) * sf::GEMM_BK);
+                const double fl = (double)g.N * (g.N + 1) * kk + 2.0 * (g.M - g.N) * (double)g.N * kk;
+                for (int side = 0; side < (lu ? 2 : 1); ++side) {     // side 0: (L) panel, side 1: U^T panel
+                    g.y_off = src + (side ? ushift : 0);
+                    g.x_off = src + ((lu && !side) ? ushift : 0);
+                    g.c_off = dst + (side ? ushift : 0);
+                    g.strict = (lu && !side) ? 1 : 0;
+                    if (count_flops) { p->flops_outer_gemm += fl; p->flops_panel_gemm += fl; }
+                    probs.push_back(g);
+                    add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K, kt_lo, kt_hi);
                 }
             }
+            if ((int64_t)gtasks.size() > g0) {
+                p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
+                p->launches.back().split = split && LS.share_cnt > 1;
+                p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
+            }
+        };
+        // Look-ahead for shared panels (several ranks): the update of block jo is cut into the FAR part (columns of the blocks
+        // 0 .. jo-2, issued right after the chain of block jo-2, shared among the ranks) and the part of block jo-1 (issued after
+        // the reduce point of block jo, executed in full by every rank: 512 columns of K).  The far part is all a block's sum over
+        // the ranks has to wait for, so that sum travels while the chain of block jo-1 runs (sf_chol_plan_factorize_distributed).
+        const bool ahead = shared && p->lookahead && LS.share_cnt > 1;
+        constexpr int KT_BLOCK = sf::OUTER_NB / sf::GEMM_BK;
+        for (int jo = 0; jo < nouter; ++jo) {
+            const int J = jo * sf::OUTER_NB;
+            if (jo > 0 && !ahead) outer_gemm(J, 0, -1, shared, true);
             if (shared) {
                 // reduce point: block column jo of every panel of the set is complete up to the sum over the group's ranks
                 if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
@@ -365,7 +384,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         sg.packed += (nsrow - J) * w;
                     }
                 }
+                sg.early = ahead && jo > 0;
                 p->segments.push_back(std::move(sg));
+                if (ahead && jo > 0) outer_gemm(J, (jo - 1) * KT_BLOCK, jo * KT_BLOCK, false, true);       // block jo-1 -> block jo, replicated
             }
             // Inside the outer block the 64-column steps are LEFT-looking as well: block column t is first
             // updated by the t block columns of this outer block already factored (K = 64 t, written once),
@@ -464,6 +485,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             }
             for (sf_long s : Sl)
                 if (J < Super[s + 1] - Super[s]) blk_ready[blk_first[s] + jo] = p->launches.size();
+            if (ahead && jo + 2 < nouter) outer_gemm(J + 2 * sf::OUTER_NB, 0, (jo + 1) * KT_BLOCK, true, true);    // blocks 0 .. jo -> block jo+2
         }
         // Schur updates of every supernode of this level into its ancestors
         const int64_t g0 = (int64_t)gtasks.size(), s0 = (int64_t)stasks.size();
@@ -766,8 +788,16 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (!p->segments.empty()) {
             int64_t mx = 1;
             for (const Segment& sg : p->segments) mx = std::max(mx, sg.packed);
-            if (hipMalloc((void**)&p->d_scratch, mx * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
-            p->bytes_device += mx * sizeof(double);
+            p->scratch_elems = mx;
+            if (hipMalloc((void**)&p->d_scratch, 2 * mx * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += 2 * mx * sizeof(double);
+            bool ok = hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) == hipSuccess;
+            for (int k = 0; k < 2; ++k) {
+                ok = ok && hipEventCreateWithFlags(&p->ev_contrib[k], hipEventDisableTiming) == hipSuccess;
+                ok = ok && hipEventCreateWithFlags(&p->ev_reduced[k], hipEventDisableTiming) == hipSuccess;
+                ok = ok && hipEventCreateWithFlags(&p->ev_unpacked[k], hipEventDisableTiming) == hipSuccess;
+            }
+            if (!ok) { rc = SF_ERR_HIP; break; }
         }
         if (p->partial) {
             std::vector<int8_t> mask(std::max<sf_long>(nsuper, 1), 0);
@@ -1102,19 +1132,30 @@ int sf_chol_plan_segment_regions(const sf_chol_plan* p, sf_long k, sf_long capac
 // gather the possibly non-zero part of segment k's regions into one contiguous buffer (strided device copies on
 // the plan's stream): ONE all-reduce per segment, and the structurally zero rows above each block's diagonal
 // (half of a square root panel) stay off the wire
+static int seg_copy(sf_chol_plan* p, const Segment& sg, double* buf, bool pack, hipStream_t st) {
+    int64_t pos = 0;
+    for (size_t i = 0; i < sg.src.size(); ++i) {
+        if (pack)
+            HIP_TRY(hipMemcpy2DAsync(buf + pos, sg.rows[i] * sizeof(double), p->d_Lsx + sg.src[i], sg.ld[i] * sizeof(double),
+                                     sg.rows[i] * sizeof(double), sg.cols[i], hipMemcpyDeviceToDevice, st));
+        else
+            HIP_TRY(hipMemcpy2DAsync(p->d_Lsx + sg.src[i], sg.ld[i] * sizeof(double), buf + pos, sg.rows[i] * sizeof(double),
+                                     sg.rows[i] * sizeof(double), sg.cols[i], hipMemcpyDeviceToDevice, st));
+        pos += sg.rows[i] * sg.cols[i];
+    }
+    return SF_OK;
+}
+
 int sf_chol_plan_segment_pack(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count) {
     if (!p || k < 0 || k >= (sf_long)p->segments.size() || !dptr || !count) return SF_ERR_ARG;
     if (p->packed_pending >= 0) return SF_ERR_ARG;           // the previous packed segment has not been run
     HIP_TRY(hipSetDevice(p->device));
     const Segment& sg = p->segments[k];
-    int64_t pos = 0;
-    for (size_t i = 0; i < sg.src.size(); ++i) {
-        HIP_TRY(hipMemcpy2DAsync(p->d_scratch + pos, sg.rows[i] * sizeof(double), p->d_Lsx + sg.src[i], sg.ld[i] * sizeof(double),
-                                 sg.rows[i] * sizeof(double), sg.cols[i], hipMemcpyDeviceToDevice, p->stream));
-        pos += sg.rows[i] * sg.cols[i];
-    }
+    double* buf = p->d_scratch + (k & 1) * p->scratch_elems;
+    int rc = seg_copy(p, sg, buf, true, p->stream);
+    if (rc) return rc;
     p->packed_pending = k;
-    *dptr = (void*)p->d_scratch;
+    *dptr = (void*)buf;
     *count = sg.packed;
     return SF_OK;
 }
@@ -1125,16 +1166,55 @@ int sf_chol_plan_factorize_segment(sf_chol_plan* p, sf_long k, int sync) {
     if (p->packed_pending >= 0) {
         if (p->packed_pending != k) return SF_ERR_ARG;
         HIP_TRY(hipSetDevice(p->device));
-        int64_t pos = 0;
-        for (size_t i = 0; i < sg.src.size(); ++i) {
-            HIP_TRY(hipMemcpy2DAsync(p->d_Lsx + sg.src[i], sg.ld[i] * sizeof(double), p->d_scratch + pos, sg.rows[i] * sizeof(double),
-                                     sg.rows[i] * sizeof(double), sg.cols[i], hipMemcpyDeviceToDevice, p->stream));
-            pos += sg.rows[i] * sg.cols[i];
-        }
+        int rc = seg_copy(p, sg, p->d_scratch + (k & 1) * p->scratch_elems, false, p->stream);
+        if (rc) return rc;
         p->packed_pending = -1;
     }
     return run_launches(p, sg.l0, sg.l1, false, k + 1 == (sf_long)p->segments.size(), sync);
 }
+
+}  // extern "C"
+
+// The pieces of the pipelined driver (sf_multi.hip).  Segment k's sum uses half k & 1 of the scratch buffer and the plan's second
+// stream:  begin (everything the sum needs has been enqueued on the main stream) -> pack on the second stream, returns the buffer for
+// the collective, which the caller issues on sf_plan_stream2 -> reduced (marks the collective's end on the second stream) ->
+// finish: the main stream waits for it, scatters the sums back and runs the segment's launches.
+int sf_seg_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count) {
+    if (!p || k < 0 || k >= (sf_long)p->segments.size() || !dptr || !count || !p->stream2) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    const int h = (int)(k & 1);
+    HIP_TRY(hipEventRecord(p->ev_contrib[h], p->stream));
+    HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_contrib[h], 0));
+    // the half's previous user (segment k - 2) has been scattered back on the main stream
+    if (p->unpacked_recorded[h]) HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_unpacked[h], 0));
+    double* buf = p->d_scratch + h * p->scratch_elems;
+    int rc = seg_copy(p, p->segments[k], buf, true, p->stream2);
+    if (rc) return rc;
+    *dptr = (void*)buf;
+    *count = p->segments[k].packed;
+    return SF_OK;
+}
+void* sf_plan_stream2(sf_chol_plan* p) { return p ? (void*)p->stream2 : nullptr; }
+int sf_seg_reduced(sf_chol_plan* p, sf_long k) {
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventRecord(p->ev_reduced[k & 1], p->stream2));
+    return SF_OK;
+}
+int sf_seg_finish(sf_chol_plan* p, sf_long k) {
+    if (!p || k < 0 || k >= (sf_long)p->segments.size()) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    const int h = (int)(k & 1);
+    const Segment& sg = p->segments[k];
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_reduced[h], 0));
+    int rc = seg_copy(p, sg, p->d_scratch + h * p->scratch_elems, false, p->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->ev_unpacked[h], p->stream));
+    p->unpacked_recorded[h] = true;
+    return run_launches(p, sg.l0, sg.l1, false, k + 1 == (sf_long)p->segments.size(), 0);
+}
+int sf_seg_early(const sf_chol_plan* p, sf_long k) { return (p && k >= 0 && k < (sf_long)p->segments.size() && p->segments[k].early) ? 1 : 0; }
+
+extern "C" {
 
 int sf_chol_plan_set_stream(sf_chol_plan* p, void* stream) {
     if (!p) return SF_ERR_ARG;

@@ -356,20 +356,35 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
     if (host_out && (rc = sf_dl_begin(p, host_out))) return rc;
     rc = sf_chol_plan_factorize_phase(p, 0, 0);
     const sf_long nseg = sf_chol_plan_num_segments(p);
-    for (sf_long k = 0; k < nseg; ++k) {
+    // Software pipeline over the segments: a segment's sum is issued on the plan's SECOND stream -- for a look-ahead segment
+    // (Segment::early) one segment ahead of its use, so the collective of block J+1 travels while the chain of block J runs on the
+    // main stream -- and the main stream picks the sums up in order.  Every rank of a group issues the group's collectives in the
+    // same order (the order of the segment list), on one stream.
+    std::vector<char> begun(nseg, 0);
+    auto begin = [&](sf_long k) -> int {
+        begun[k] = 1;
         sf_comm* gc = group_comm(comm, p->segments[k].mask);
-        if (!gc && !rc) rc = SF_ERR_ARG;
-        if (rc) {
-            // emulated ranks hand-shake on the host: a failed rank keeps taking part so that the others return too
-            if (gc && gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, (void*)p->stream);
-            continue;
-        }
+        if (!gc) return SF_ERR_ARG;
         void* buf = nullptr;
         sf_long cnt = 0;
-        rc = sf_chol_plan_segment_pack(p, k, &buf, &cnt);
-        if (rc) { --k; continue; }      // re-enter the loop for this segment in the failed state
-        rc = sf_comm_allreduce_sum(gc, buf, cnt, (void*)p->stream);
-        if (!rc) rc = sf_chol_plan_factorize_segment(p, k, 0);
+        int r = sf_seg_begin(p, k, &buf, &cnt);
+        // emulated ranks hand-shake on the host: a failed rank keeps taking part so that the others return too
+        if (r) { if (gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, sf_plan_stream2(p)); return r; }
+        r = sf_comm_allreduce_sum(gc, buf, cnt, sf_plan_stream2(p));
+        return r ? r : sf_seg_reduced(p, k);
+    };
+    for (sf_long k = 0; k < nseg; ++k) {
+        if (rc) {
+            if (!begun[k]) {
+                sf_comm* gc = group_comm(comm, p->segments[k].mask);
+                if (gc && gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, sf_plan_stream2(p));
+                begun[k] = 1;
+            }
+            continue;
+        }
+        if (!begun[k]) rc = begin(k);
+        if (!rc && k + 1 < nseg && !begun[k + 1] && sf_seg_early(p, k + 1)) rc = begin(k + 1);
+        if (!rc) rc = sf_seg_finish(p, k);
     }
     int rc_dl = SF_OK;
     if (host_out) rc_dl = sf_dl_end(p);         // (also releases the copy workers when rc != 0)

@@ -45,6 +45,10 @@ struct Segment {
     // `ld` apart, starting at `src` -- what sf_chol_plan_segment_pack gathers into one contiguous buffer
     std::vector<int64_t> src, rows, cols, ld;
     int64_t packed = 0;                    // doubles in the packed buffer
+    // look-ahead schedule: every additive contribution to these block columns except the one of the block column just before
+    // them (which the segment's own first launch adds, replicated) is enqueued before the PREVIOUS segment starts, so the sum
+    // over the ranks may run beside the previous segment's chain
+    bool early = false;
 };
 
 #define HIP_TRY(expr)                                                                       \
@@ -127,7 +131,12 @@ struct sf_chol_plan {
     int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
     std::vector<Segment> segments;
     std::vector<uint32_t> all_masks;    // every group of the factorization (all ranks build the same sorted list)
-    double* d_scratch = nullptr;   // packed segment buffer (max over the segments)
+    double* d_scratch = nullptr;   // packed segment buffers (2 x max over the segments: segment k uses half k & 1)
+    int64_t scratch_elems = 0;
+    bool lookahead = true;         // shared top panels: outer GEMM split into a far part (ahead of the previous chain) and the last block's
+    hipStream_t stream2 = nullptr; // the collectives of look-ahead segments and their pack copies
+    hipEvent_t ev_contrib[2] = {nullptr, nullptr}, ev_reduced[2] = {nullptr, nullptr}, ev_unpacked[2] = {nullptr, nullptr};
+    bool unpacked_recorded[2] = {false, false};
     int64_t packed_pending = -1;   // segment whose packed buffer has to be scattered back before it runs
     bool own_stream = true;
     int8_t* d_loadmask = nullptr;
@@ -197,3 +206,9 @@ struct sf_chol_plan {
 // sf_dl_end publishes what is left, waits for the workers and returns SF_OK or the first error.
 int sf_dl_begin(sf_chol_plan* p, double* host_out);
 int sf_dl_end(sf_chol_plan* p);
+// pipelined segment sums (sf_chol_plan.hip), used by sf_chol_plan_factorize_distributed
+int sf_seg_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count);
+void* sf_plan_stream2(sf_chol_plan* p);
+int sf_seg_reduced(sf_chol_plan* p, sf_long k);
+int sf_seg_finish(sf_chol_plan* p, sf_long k);
+int sf_seg_early(const sf_chol_plan* p, sf_long k);

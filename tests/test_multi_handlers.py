@@ -50,6 +50,41 @@ def test_all_handlers_factorize_one_matrix_emulated(oracle, monkeypatch, nh):
     _chol_case(oracle, 24, nh)
 
 
+@pytest.mark.parametrize("nh,lookahead", [(2, "1"), (4, "1"), (2, "0")])
+def test_lookahead_schedule_three_outer_blocks(oracle, monkeypatch, nh, lookahead):
+    """34^3: the root separator has 1156 columns = 3 outer blocks, so the look-ahead schedule of a shared panel has all its
+    parts: the far part of block 2's update issued after the chain of block 0 (split over the ranks), the parts of the block
+    just before (replicated, after the reduce point), sums issued one segment ahead on the second stream.  SF_LOOKAHEAD=0 is
+    the older schedule (whole update split, sum in line)."""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", str(nh))
+    monkeypatch.setenv("SF_LOOKAHEAD", lookahead)
+    _chol_case(oracle, 34, nh)
+
+
+def test_lookahead_schedule_lu(oracle, monkeypatch):
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", "2")
+    N = 33
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=13)
+    perm = nd_perm_py(N, N, N)
+    common = sf.CommonInfo(dev_slot_size=8 << 30)
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    mi.factorize(common)
+    assert mi.validate() <= TOL_RESIDUAL
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 8 << 30, "lu", False)
+    assert np.diff(S.Super).max() > 1024
+    ref, info, _ = oracle.lu_factorize(S)
+    assert rel_err(mi.array("Lsx", S.xsize).copy(), ref) <= TOL_FACTOR
+    mi.cleanup()
+    common.close()
+
+
 def test_all_handlers_lu_emulated(oracle, monkeypatch):
     if sf.device_count() != 1:
         pytest.skip("emulated handlers are for one-GPU boxes")
