@@ -90,28 +90,30 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(64)
-k_potrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ info) {
-    const PotrfTask t = tasks[blockIdx.x];
+// W = the smallest of 8 / 16 / 32 / 64 that holds the block: the elimination is fully unrolled over W columns (registers), and
+// at the bottom levels of a 2-D problem most blocks have a handful of columns -- with W = 64 for all, a 3-column block cost the
+// 2,016 FMAs + 4,032 v_readlane of a 64-column one (config 3: 21,000 such blocks = 0.30 ms, compute-bound on padding)
+template <int W>
+__device__ __forceinline__ void potrf_block_w(const PotrfTask& t, double* __restrict__ Lsx, int* __restrict__ info) {
     double* A = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
     const int b = t.b;
     const int lane = threadIdx.x;
     const int64_t ld = t.ld;
 
-    double a[NB];
+    double a[W];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
+    for (int c = 0; c < W; ++c) {
         double v = (c == lane) ? 1.0 : 0.0;
         if (lane < b && c <= lane) v = A[lane + c * ld];
         a[c] = v;
     }
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < W; ++j) {
         const double djj = readlane_f64(a[j], j);
         bad = bad || !(djj > 0.0);          // also catches NaN; padded rows have djj = 1
         // 1/sqrt(djj) from v_rsq_f64 + two Newton steps (full fp64 accuracy for normal inputs), d = djj * rinv:
-        // the IEEE sqrt and divide sequences are ~10x longer and sit on the 64-step sequential critical path
+        // the IEEE sqrt and divide sequences are ~10x longer and sit on the sequential critical path
         double rinv = __builtin_amdgcn_rsq(djj);
         rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
         rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
@@ -119,12 +121,21 @@ k_potrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int
         const double lj = (lane == j) ? d : ((lane > j) ? a[j] * rinv : 0.0);
         a[j] = lj;
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) a[c] -= lj * readlane_f64(lj, c);
+        for (int c = j + 1; c < W; ++c) a[c] -= lj * readlane_f64(lj, c);
     }
     if (bad && lane == 0) atomicOr(info, 1);
 #pragma unroll
-    for (int c = 0; c < NB; ++c)
+    for (int c = 0; c < W; ++c)
         if (lane < b && c <= lane) A[lane + c * ld] = a[c];
+}
+
+__global__ void __launch_bounds__(64)
+k_potrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ info) {
+    const PotrfTask t = tasks[blockIdx.x];
+    if (t.b <= 8) potrf_block_w<8>(t, Lsx, info);
+    else if (t.b <= 16) potrf_block_w<16>(t, Lsx, info);
+    else if (t.b <= 32) potrf_block_w<32>(t, Lsx, info);
+    else potrf_block_w<NB>(t, Lsx, info);
 }
 
 void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hipStream_t st) {
@@ -193,39 +204,30 @@ __device__ __forceinline__ void getrf_panel_wave(double (&a)[W], int lane, int J
     }
 }
 
-template <bool RCP>
-__device__ __forceinline__ int getrf_wave(double (&a)[NB], int lane, int b, double tol, double eps, bool& bad, int& nperturbed) {
-    int pos = lane;
-    bool active = lane < b;
-    getrf_panel_wave<RCP, NB>(a, lane, 0, b, tol, eps, bad, nperturbed, pos, active, nullptr);
-    return pos;
-}
-
 // The block lives in two panels: D(r,c), c < r (L, unit diagonal implied) in the L panel at (diag+r, diag+c); D(r,c), c >= r
 // (U) in the U^T panel at (diag+c, diag+r).
-__global__ void __launch_bounds__(64)
-k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int64_t u_shift, int* __restrict__ info, PivotCtl pc) {
-    const PotrfTask t = tasks[blockIdx.x];
+template <int W>
+__device__ __forceinline__ void getrf_block_w(const PotrfTask& t, double* __restrict__ Lsx, int64_t u_shift, int* __restrict__ info, const PivotCtl& pc) {
     double* PLd = Lsx + t.panel + t.diag + (int64_t)t.diag * t.ld;
     double* PUd = PLd + u_shift;
     const int b = t.b;
     const int lane = threadIdx.x;
     const int64_t ld = t.ld;
 
-    double a[NB];
+    double a[W];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
+    for (int c = 0; c < W; ++c) {
         double v = (c == lane) ? 1.0 : 0.0;
         if (lane < b && c < b) v = (c < lane) ? PLd[lane + c * ld] : PUd[c + lane * ld];
         a[c] = v;
     }
-    bool bad = false;
-    int np = 0;
-    const int pos = getrf_wave<false>(a, lane, b, pc.tol, pc.eps, bad, np);
+    bool bad = false, active = lane < b;
+    int np = 0, pos = lane;
+    getrf_panel_wave<false, W>(a, lane, 0, b, pc.tol, pc.eps, bad, np, pos, active, nullptr);
     if (bad && lane == 0) atomicOr(info, 1);
     if (np > 0 && lane == 0) atomicAdd(pc.nperturb, np);
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
+    for (int c = 0; c < W; ++c) {
         if (lane < b && c < b) {
             if (c < pos) PLd[pos + c * ld] = a[c]; else PUd[c + pos * ld] = a[c];
         }
@@ -235,6 +237,16 @@ k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int
         pc.pivpos[g0 + lane] = g0 + pos;
         pc.pivinv[g0 + pos] = g0 + lane;
     }
+}
+
+// width-specialised like k_potrf_block
+__global__ void __launch_bounds__(64)
+k_getrf_block(const PotrfTask* __restrict__ tasks, double* __restrict__ Lsx, int64_t u_shift, int* __restrict__ info, PivotCtl pc) {
+    const PotrfTask t = tasks[blockIdx.x];
+    if (t.b <= 8) getrf_block_w<8>(t, Lsx, u_shift, info, pc);
+    else if (t.b <= 16) getrf_block_w<16>(t, Lsx, u_shift, info, pc);
+    else if (t.b <= 32) getrf_block_w<32>(t, Lsx, u_shift, info, pc);
+    else getrf_block_w<NB>(t, Lsx, u_shift, info, pc);
 }
 
 void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, PivotCtl pc, hipStream_t st) {
@@ -1220,7 +1232,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         //            with the panel's multipliers (LDS broadcasts);
         //   trailing every wave its 16 rows x the columns to the right with MFMA out of LDS, the multipliers of rows that are
         //            already used (in this or an earlier panel) masked to zero, the U12 rows gathered through the pivot list.
-        // The unblocked form (getrf_wave: a 64-value row per lane, 4,000 v_readlane pairs on the critical path) cost 68 us per
+        // The unblocked form (a 64-value row per lane in getrf_panel_wave<true, 64>, 4,000 v_readlane pairs on the critical path) cost 68 us per
         // step and 256 VGPRs; see DESIGN 6b for the figures of this one.
         __shared__ int s_piv[NB], s_pos[NB];
         if (tid < NB) s_pos[tid] = -1;
