@@ -87,3 +87,34 @@ def test_bad_inputs_are_rejected():
     bad[3] = n + 5
     with pytest.raises(sf.SparseFrameError):
         sf.analyze(n, Cp, bad, Cx, None, 1 << 30)
+
+
+def test_threaded_analysis_is_bit_identical_to_sequential(tmp_path):
+    """the triangles of P A P^T are built by parallel stable bucket sorts (SF_ANALYZE_THREADS, read once per process): every
+    integer and value array must be identical to the one-thread result (and therefore to the reference's sequential fill,
+    which the oracle comparisons above pin).  Two child processes, 1 and 8 threads, Cholesky and unsymmetric LU."""
+    import hashlib, json, os, subprocess, sys
+    code = r'''
+import hashlib, importlib, json, os, sys
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+sf = importlib.import_module("sparse-matrix-factorization-library_amd")
+out = {}
+g = 34
+n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
+S = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g), 1 << 30)
+for k in ("Lp", "Li", "LTp", "LTi", "Super", "Lsi", "Perm", "Lx", "LTx"):
+    out["chol." + k] = hashlib.sha256(getattr(S, k).tobytes()).hexdigest()
+n, Cp, Ci, Cx = sf.gen.unsymmetric_stencil(g, g, g, seed=4)
+S = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g), 1 << 30, "lu", False)
+for k in ("Lp", "Li", "LTi", "Up", "Ui", "UTp", "UTi", "Super", "Lsi", "Lx", "Ux", "UTx"):
+    out["lu." + k] = hashlib.sha256(getattr(S, k).tobytes()).hexdigest()
+print(json.dumps(out))
+'''
+    res = []
+    for T in ("1", "8"):
+        env = dict(os.environ, SF_ANALYZE_THREADS=T)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1]
