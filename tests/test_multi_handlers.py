@@ -63,6 +63,30 @@ def test_lookahead_schedule_three_outer_blocks(oracle, monkeypatch, nh, lookahea
     _chol_case(oracle, 34, nh)
 
 
+@pytest.mark.parametrize("nh,N", [(2, 64), (4, 64), (8, 96)])
+def test_emulated_handlers_large_by_residual(monkeypatch, nh, N):
+    """64^3 over 2 / 4 emulated handlers: the root separator has 8 outer blocks, its children 4 (groups of 2 at nh = 4), and the
+    split Schur launches of the top levels have thousands of tiles per rank window, i.e. the dynamic whole-tile rounds of k_gemm run
+    inside a rank's unit window.  Too big for the oracle in test time: checked by the residual of the reference's validate() on the
+    factor the ranks copied back (every entry of Lsx written)."""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", str(nh))
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    common = sf.CommonInfo(dev_slot_size=8 << 30)
+    assert common.c.numGPU == nh
+    mi = sf.MatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx)
+    mi.set_perm(sf.grid_nd_perm(N, N, N))
+    mi.analyze(common)
+    xsize = int(mi.c.xsize)
+    C.memset(mi.c.Lsx, 0xff, 8 * xsize)
+    mi.factorize(common)
+    assert mi.validate() <= TOL_RESIDUAL
+    mi.cleanup()
+    common.close()
+
+
 def test_lookahead_schedule_lu(oracle, monkeypatch):
     if sf.device_count() != 1:
         pytest.skip("emulated handlers are for one-GPU boxes")
