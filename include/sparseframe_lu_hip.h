@@ -122,6 +122,14 @@ int SparseFrame_cleanup_matrix(struct matrix_info_struct *matrix_info);
 /* layout probe, as sf_abi_layout() of the Cholesky library */
 long sf_lu_abi_layout(const char *name);
 
+/* replaces C:368-398 (LU: the same functions of LU/Source/SparseFrame.c): the driver's list of matrixThreadNum matrix_info objects */
+int SparseFrame_allocate_matrix(struct common_info_struct *common_info, struct matrix_info_struct **matrix_info_list_ptr);
+int SparseFrame_free_matrix(struct common_info_struct *common_info, struct matrix_info_struct **matrix_info_list_ptr);
+/* replaces C:3323-3467, the reference's public entry point (Include/SparseFrame.h:43; Demo/demo.c calls it): argv[1..] are
+ * MatrixMarket files; each is read, analysed, factorized on the GPU(s), solved and validated by one of up to two matrix threads
+ * that share the handler list; prints the reference's report lines.  Returns the number of matrices that failed (the reference: 0). */
+int SparseFrame(int argc, char **argv);
+
 #ifdef __cplusplus
 }
 #endif

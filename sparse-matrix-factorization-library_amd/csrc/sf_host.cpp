@@ -3,7 +3,13 @@
 // Reference files: Cholesky/Source/SparseFrame.c (C:), Cholesky/Include/info.h (I:).
 #include <sparseframe_hip.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <mutex>
+#include <thread>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -457,5 +463,7 @@ int SparseFrame_cleanup_matrix(struct matrix_info_struct* mi) {  // C:3268-3321
     mi->residual = res;
     return 0;
 }
+
+#include "sf_driver.inc"
 
 }  // extern "C"

@@ -3,7 +3,13 @@
 // Reference file: LU/Source/SparseFrame.c ("L:").
 #include <sparseframe_lu_hip.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <mutex>
+#include <thread>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -323,5 +329,7 @@ int SparseFrame_cleanup_matrix(struct matrix_info_struct* mi) {   // L:3860-3922
     mi->readTime = rt; mi->analyzeTime = at; mi->factorizeTime = ft; mi->solveTime = st; mi->residual = res;
     return 0;
 }
+
+#include "sf_driver.inc"
 
 }  // extern "C"

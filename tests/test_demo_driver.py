@@ -1,0 +1,95 @@
+"""The reference's public entry point int SparseFrame(int argc, char **argv) (Include/SparseFrame.h:43) and its demo program
+(Demo/demo.c): MatrixMarket files in, the reference's report out.  BASELINE config 1 is exactly this path on the 2-D 5-point
+Laplacian 100 x 100.  examples/demo.c is linked against each of the two libraries (sf_demo, sf_demo_lu), as the reference builds
+one libSparseFrame.so per method."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import sf, gen
+
+PKG = os.path.dirname(os.path.abspath(sf.__file__))
+DEMO = os.path.join(PKG, "sf_demo")
+DEMO_LU = os.path.join(PKG, "sf_demo_lu")
+
+
+def _run(exe, files):
+    return subprocess.run([exe] + files, capture_output=True, text=True, timeout=600)
+
+
+def test_demo_binaries_exist_and_report_usage():
+    for exe in (DEMO, DEMO_LU):
+        assert os.path.exists(exe), "built by make -C sparse-matrix-factorization-library_amd/csrc (__graft_entry__.build())"
+        r = _run(exe, [])
+        assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_demo_without_a_gpu_fails_loudly(tmp_path):
+    if sf.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    n, Cp, Ci, Cx = gen.laplacian_lower(10, 10)
+    path = str(tmp_path / "lap.mtx")
+    gen.write_matrix_market(path, n, Cp, Ci, Cx, symmetric=True)
+    r = _run(DEMO, [path])
+    assert r.returncode == 1
+    assert "no CPU fallback" in r.stderr and "SparseFrame_factorize failed" in r.stderr
+    assert "residual" not in r.stdout
+
+
+def _residuals(out):
+    return [float(x) for x in re.findall(r"residual \(\|Ax-b\|\)/\(\|A\|\|x\|\+\|b\|\): ([0-9.eE+-]+)", out)]
+
+
+@pytest.mark.gpu
+def test_demo_config1_and_friends(tmp_path):
+    """config 1 (2-D 5-point Laplacian 100 x 100), a 3-D 7-point Laplacian and a 2-D wide stencil through sf_demo: three files,
+    two matrix threads sharing one handler list, default ordering (the built-in nested dissection: METIS is absent)"""
+    files = []
+    for name, (n, Cp, Ci, Cx) in (("lap2d_100", gen.laplacian_lower(100, 100)), ("lap3d_16", gen.laplacian_lower(16, 16, 16)),
+                                  ("stencil2d_60", gen.stencil_spd_lower(60, 60))):
+        p = str(tmp_path / (name + ".mtx"))
+        gen.write_matrix_market(p, n, Cp, Ci, Cx, symmetric=True)
+        files.append(p)
+    r = _run(DEMO, files)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Num of matrices = 3" in r.stdout and "Total computing time" in r.stdout
+    for name in ("lap2d_100.mtx", "lap3d_16.mtx", "stencil2d_60.mtx"):
+        assert "Matrix name:    " + name in r.stdout
+    res = _residuals(r.stdout)
+    assert len(res) == 3 and max(res) <= 1e-13
+    for key in ("Read time:", "Analyze time:", "Factorize time:", "Solve time:"):
+        assert r.stdout.count(key) == 3
+
+
+@pytest.mark.gpu
+def test_demo_lu(tmp_path):
+    """the LU library's SparseFrame(): a general (unsymmetric) MatrixMarket file and a symmetric one"""
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(12, 12, 12, seed=3)
+    p1 = str(tmp_path / "unsym_12.mtx")
+    gen.write_matrix_market(p1, n, Cp, Ci, Cx, symmetric=False)
+    n, Cp, Ci, Cx = gen.laplacian_lower(30, 30)
+    p2 = str(tmp_path / "lap2d_30.mtx")
+    gen.write_matrix_market(p2, n, Cp, Ci, Cx, symmetric=True)
+    r = _run(DEMO_LU, [p1, p2])
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _residuals(r.stdout)
+    assert len(res) == 2 and max(res) <= 1e-13
+
+
+@pytest.mark.gpu
+def test_demo_reports_a_bad_matrix_and_goes_on(tmp_path):
+    """an indefinite matrix fails in factorize (the reference would print a garbage residual); the other file is still processed"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(20, 20)
+    good = str(tmp_path / "good.mtx")
+    gen.write_matrix_market(good, n, Cp, Ci, Cx, symmetric=True)
+    Cx = Cx.copy()
+    Cx[Cp[n // 2]] = -4.0            # a negative diagonal entry
+    bad = str(tmp_path / "bad.mtx")
+    gen.write_matrix_market(bad, n, Cp, Ci, Cx, symmetric=True)
+    r = _run(DEMO, [bad, good])
+    assert r.returncode == 1
+    assert "bad.mtx: SparseFrame_factorize failed with code 4" in r.stderr
+    assert len(_residuals(r.stdout)) == 1 and "Matrix name:    good.mtx" in r.stdout
