@@ -120,3 +120,45 @@ def test_matrix_market_drops_explicit_zeros(tmp_path):
     mi.read(p)
     assert mi.c.nzmax == 4           # reference C:496 skips the explicit zero
     assert list(mi.array("Cp", 4)) == [0, 1, 3, 4]
+
+
+@pytest.mark.parametrize("text,ok,nz", [
+    # integer field, entries of the UPPER triangle, blank lines, several comment lines
+    ("%%MatrixMarket matrix coordinate integer symmetric\n% a\n%b\n\n3 3 4\n1 1 2\n1 2 -1\n\n2 2 3\n3 3 4\n", True, 4),
+    # general (unsymmetric) real
+    ("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.5\n2 1 -0.5\n2 2 2.5\n", True, 3),
+    # the reference treats anything but `real` as complex and then needs an imaginary part (C:436-440, :480): rejected here
+    ("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1.0 0.0\n", False, 0),
+    # not MatrixMarket (C:421)
+    ("3 3 1\n1 1 1.0\n", False, 0),
+    # size line incomplete (C:449)
+    ("%%MatrixMarket matrix coordinate real symmetric\n3 3\n1 1 1.0\n", False, 0),
+    # entry without a value (C:474 'invalid matrix entry')
+    ("%%MatrixMarket matrix coordinate real symmetric\n2 2 2\n1 1 1.0\n2 2\n", False, 0),
+    # more entries than announced (C:488 'nzmax exceeded')
+    ("%%MatrixMarket matrix coordinate real symmetric\n2 2 1\n1 1 1.0\n2 2 1.0\n", False, 0),
+    # index out of range / rectangular: undefined behaviour in the reference, an error here
+    ("%%MatrixMarket matrix coordinate real symmetric\n2 2 1\n3 1 1.0\n", False, 0),
+    ("%%MatrixMarket matrix coordinate real general\n2 3 1\n1 1 1.0\n", False, 0),
+], ids=["integer-upper-blank", "general", "complex", "no-banner", "short-size-line", "short-entry", "too-many", "out-of-range", "rectangular"])
+def test_matrix_market_reader_edge_cases(tmp_path, text, ok, nz):
+    """SparseFrame_read_matrix against the reference reader's behaviour (C:400-513) on well- and ill-formed files"""
+    p = tmp_path / "m.mtx"
+    p.write_text(text)
+    mi = sf.MatrixInfo()
+    if not ok:
+        with pytest.raises(sf.SparseFrameError):
+            mi.read(p)
+        return
+    mi.read(p)
+    assert mi.c.nzmax == nz and mi.c.isComplex == 0
+    assert mi.c.isSymmetric == (1 if "symmetric" in text.splitlines()[0] else 0)
+    Cp = mi.array("Cp", mi.c.nrow + 1)
+    assert Cp[0] == 0 and Cp[-1] == nz and np.all(np.diff(Cp) >= 0)
+    mi.cleanup()
+
+
+def test_matrix_market_missing_file(tmp_path):
+    mi = sf.MatrixInfo()
+    with pytest.raises(sf.SparseFrameError):
+        mi.read(tmp_path / "does_not_exist.mtx")
