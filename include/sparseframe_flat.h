@@ -120,6 +120,8 @@ int sf_chol_plan_factorize_to_host(sf_chol_plan *plan, const sf_float *Lx, const
 void *sf_chol_plan_factor_device_ptr(sf_chol_plan *plan);
 /* device-side supernodal solve with the resident factor: x <- (L L^T)^{-1} b, permuted space */
 int sf_chol_plan_solve(sf_chol_plan *plan, const sf_float *b_host, sf_float *x_host);
+/* values [e_begin, e_end) of the factor in the reference layout (whole plans only) */
+int sf_chol_plan_get_factor_range(sf_chol_plan *plan, sf_long e_begin, sf_long e_end, sf_float *out);
 /* SparseFrame_validate on the device (C:3141-3266; LU plans: L:3702-3858): b_i = 1 + i/n, solve with the resident factor,
  * r = A x - b from the plan's copy of the matrix values, *residual = |r|_inf / (|A|_1 |x|_inf + |b|_inf).  x_host may be NULL. */
 int sf_chol_plan_validate(sf_chol_plan *plan, sf_float *residual, sf_float *x_host);
@@ -273,6 +275,15 @@ int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_inf
                           const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
                           const sf_float *Lx, const sf_float *Ux, sf_float *Lsx_out,
                           sf_long *PivOut /* LU: row positions after the in-block interchanges (n entries), or NULL */);
+
+/* The struct path's solve with the RESIDENT factor: after SparseFrame_factorize on one handler the factor is still in that handler's
+ * cached plan; SparseFrame_solve_supernodal (which only receives matrix_info) asks here, by the address of the host copy.  Solves on
+ * the device (b, x in the permuted numbering, n doubles each way) when the plan still holds THAT factorization and a sample of the
+ * host copy (three windows of 512 values) still equals the device's; otherwise returns SF_ERR_ARG and the caller solves on the host
+ * as the reference does (C:3036-3139).  SF_SOLVE=host in the environment forces the host solve.  forget: the host copy is being freed. */
+int sf_handlers_solve_resident(const sf_float *Lsx_host, const sf_float *b, sf_float *x);
+void sf_handlers_forget(const sf_float *Lsx_host);
+int64_t sf_handlers_resident_solves(void);     /* how many solves were served from a resident factor so far (tests) */
 
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
 int sf_device_count(void);

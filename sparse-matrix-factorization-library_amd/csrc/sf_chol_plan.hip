@@ -1469,6 +1469,27 @@ int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
     return SF_OK;
 }
 
+// values [e_begin, e_end) of the factor in the reference layout (a whole plan only): what the struct path samples to make sure a
+// host copy still is what the device holds before it solves with the resident factor
+int sf_chol_plan_get_factor_range(sf_chol_plan* p, sf_long e_begin, sf_long e_end, sf_float* out) {
+    if (!p || p->partial || e_begin < 0 || e_end > p->xsize || e_end < e_begin || (!out && e_end > e_begin)) return SF_ERR_ARG;
+    if (e_end == e_begin) return SF_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->lu) {
+        HIP_TRY(hipMemcpyAsync(out, p->d_Lsx + e_begin, (e_end - e_begin) * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return SF_OK;
+    }
+    double* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (e_end - e_begin) * sizeof(double)));
+    sf::launch_pack_lu(p->d_Super, p->d_Lsip, p->d_Xp, p->d_Lsxp, (int32_t)p->nsuper, p->d_Lsx, p->d_Lsx + p->xC, tmp, e_begin, e_end, p->stream);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipMemcpyAsync(out, tmp, (e_end - e_begin) * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    hipError_t e3 = hipStreamSynchronize(p->stream);
+    (void)hipFree(tmp);
+    return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? SF_OK : SF_ERR_HIP;
+}
+
 int sf_lu_plan_set_pivoting(sf_lu_plan* p, double tol, double perturb) {
     if (!p || !p->lu || !(tol >= 0.0) || tol > 1.0 || !(perturb >= 0.0)) return SF_ERR_ARG;
     p->piv_tol = tol;

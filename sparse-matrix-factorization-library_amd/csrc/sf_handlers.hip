@@ -11,9 +11,11 @@
 #include <sparseframe_hip.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "sf_plan_internal.h"
@@ -71,6 +73,23 @@ PlanKey make_key(int lu, sf_long n, sf_long nsuper, const sf_long* Super, const 
     return k;
 }
 
+struct HandlerState;
+// host copies of factors that a single handler's cached plan still holds on the device (sf_handlers_solve_resident)
+struct Resident { sf_chol_plan* plan; int epoch; HandlerState* st; };
+std::mutex g_res_mu;
+std::unordered_map<const void*, Resident> g_resident;
+int64_t g_resident_solves = 0;      // solves served from a resident factor (tests)
+void forget_plan(sf_chol_plan* plan) {
+    std::lock_guard<std::mutex> g(g_res_mu);
+    for (auto it = g_resident.begin(); it != g_resident.end();)
+        if (it->second.plan == plan) it = g_resident.erase(it); else ++it;
+}
+void destroy_plan(sf_chol_plan* plan) {
+    if (!plan) return;
+    forget_plan(plan);
+    sf_chol_plan_destroy(plan);
+}
+
 // all handlers of a list working on ONE matrix (the reference runs numGPU + numCPU workers inside
 // SparseFrame_factorize_supernodal, C:2267): communicators and the per-rank distributed plans, hung off handler 0
 struct MultiState {
@@ -95,7 +114,7 @@ struct HandlerState {
     uint64_t builds = 0;                // plans built by this handler (cache misses)
     MultiState* multi = nullptr;        // handler 0 only
     ~HandlerState() {
-        for (Entry& e : cache) sf_chol_plan_destroy(e.plan);
+        for (Entry& e : cache) destroy_plan(e.plan);
         delete multi;
     }
 };
@@ -296,12 +315,12 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
             size_t lru = 0;
             for (size_t i = 1; i < S.cache.size(); ++i)
                 if (S.cache[i].stamp < S.cache[lru].stamp) lru = i;
-            sf_chol_plan_destroy(S.cache[lru].plan);
+            destroy_plan(S.cache[lru].plan);
             S.cache.erase(S.cache.begin() + lru);
         }
         int rc = create();
         if ((rc == SF_ERR_ALLOC || rc == SF_ERR_HIP) && !S.cache.empty()) {
-            for (HandlerState::Entry& e : S.cache) sf_chol_plan_destroy(e.plan);
+            for (HandlerState::Entry& e : S.cache) destroy_plan(e.plan);
             S.cache.clear();
             (void)hipGetLastError();
             rc = create();
@@ -311,8 +330,13 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
         ++S.builds;
     }
     const auto tk2 = std::chrono::steady_clock::now();
+    forget_plan(plan);              // whatever host copy this plan's factor stood for is about to be overwritten on the device
     int rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
     if (!rc && lu && PivOut) rc = sf_lu_plan_get_pivots(plan, PivOut);
+    if (!rc) {
+        std::lock_guard<std::mutex> g(g_res_mu);
+        g_resident[(const void*)Lsx_out] = Resident{plan, plan->epoch, H.st};
+    }
     if (trace) {
         const auto tk3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -320,6 +344,45 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
                 ms(tk0, tk1), ms(tk1, tk2), ms(tk2, tk3));
     }
     return rc;
+}
+
+// SparseFrame_solve_supernodal's fast path: see sparseframe_flat.h.  g_res_mu is held for the whole solve: a factorization or a
+// destruction of the same plan waits in forget_plan until it is over (lock order there: handler lock, then g_res_mu; here only
+// g_res_mu), so nobody else touches the plan meanwhile.
+int sf_handlers_solve_resident(const sf_float* Lsx_host, const sf_float* b, sf_float* x) {
+    if (!Lsx_host || !b || !x) return SF_ERR_ARG;
+    if (const char* e = getenv("SF_SOLVE"))
+        if (!strcmp(e, "host")) return SF_ERR_ARG;
+    std::lock_guard<std::mutex> g(g_res_mu);
+    auto it = g_resident.find((const void*)Lsx_host);
+    if (it == g_resident.end()) return SF_ERR_ARG;
+    sf_chol_plan* plan = it->second.plan;
+    if (plan->epoch != it->second.epoch || plan->partial) { g_resident.erase(it); return SF_ERR_ARG; }
+    // the host copy must still be what the device holds (it came from there bit by bit): three windows of 512 values
+    const sf_long xs = plan->xsize, w = std::min<sf_long>(512, xs);
+    const sf_long starts[3] = {0, std::max<sf_long>(0, xs / 2 - w / 2), xs - w};
+    std::vector<double> dev((size_t)w);
+    for (sf_long st : starts) {
+        if (sf_chol_plan_get_factor_range(plan, st, st + w, dev.data()) != SF_OK ||
+            memcmp(dev.data(), Lsx_host + st, (size_t)w * sizeof(double)) != 0) {
+            g_resident.erase(it);
+            return SF_ERR_ARG;
+        }
+    }
+    const int rc = plan->lu ? sf_lu_plan_solve(plan, b, x) : sf_chol_plan_solve(plan, b, x);
+    if (!rc) ++g_resident_solves;
+    return rc;
+}
+
+int64_t sf_handlers_resident_solves(void) {
+    std::lock_guard<std::mutex> g(g_res_mu);
+    return g_resident_solves;
+}
+
+void sf_handlers_forget(const sf_float* Lsx_host) {
+    if (!Lsx_host) return;
+    std::lock_guard<std::mutex> g(g_res_mu);
+    g_resident.erase((const void*)Lsx_host);
 }
 
 int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_allocate(common, list); }

@@ -241,6 +241,13 @@ int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_str
 int SparseFrame_solve_supernodal(struct matrix_info_struct* mi) {
     if (!mi || !mi->Lsx || !mi->Bx || !mi->Xx) return 1;
     const double t0 = wall_seconds();
+    // the factor SparseFrame_factorize copied into Lsx is normally still resident in the handler's plan: solve there (two sweeps
+    // over the factor in HBM instead of host memory).  Falls through to the reference's host solve when it is not (several
+    // handlers, plan evicted or re-used, Lsx changed by the caller, SF_SOLVE=host).
+    if (sf_handlers_solve_resident(mi->Lsx, mi->Bx, mi->Xx) == SF_OK) {
+        mi->solveTime = wall_seconds() - t0;
+        return 0;
+    }
     double* x = mi->Xx;
     memcpy(x, mi->Bx, mi->nrow * sizeof(double));
     for (sf_long s = 0; s < mi->nsuper; ++s) {
@@ -315,6 +322,7 @@ int SparseFrame_validate(struct matrix_info_struct* mi) {   // L:3702-3858
 
 int SparseFrame_cleanup_matrix(struct matrix_info_struct* mi) {   // L:3860-3922
     if (!mi) return 1;
+    sf_handlers_forget(mi->Lsx);
     SF_FREE(Tj); SF_FREE(Ti); SF_FREE(Tx); SF_FREE(Cp); SF_FREE(Ci); SF_FREE(Cx);
     SF_FREE(CPCTp); SF_FREE(CPCTi);
     SF_FREE(Lp); SF_FREE(Li); SF_FREE(Lx); SF_FREE(LTp); SF_FREE(LTi); SF_FREE(LTx);
