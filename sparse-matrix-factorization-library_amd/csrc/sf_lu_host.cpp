@@ -130,7 +130,13 @@ int SparseFrame_read_matrix(struct matrix_info_struct* mi) {
         while (getline(&line, &cap, f) != -1) {
             if (line[0] == '\n' || line[0] == 0) continue;
             long i, j; double x;
-            if (sscanf(line, "%ld %ld %lg", &i, &j, &x) < 3) { bad = true; break; }
+            {   // "%ld %ld %lg" by hand: strtol / strtod are several times faster than sscanf on files of 10^7 lines
+                char *e1, *e2, *e3;
+                i = strtol(line, &e1, 10);
+                j = strtol(e1, &e2, 10);
+                x = strtod(e2, &e3);
+                if (e1 == line || e2 == e1 || e3 == e2) { bad = true; break; }
+            }
             if (x != 0) {
                 if ((long)Tx.size() >= nzmax || i < 1 || j < 1 || i > nrow || j > ncol) { bad = true; break; }
                 Ti.push_back(i - 1); Tj.push_back(j - 1); Tx.push_back(x);

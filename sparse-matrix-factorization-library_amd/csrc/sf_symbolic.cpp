@@ -12,6 +12,7 @@
 // The code is organised differently (separate passes over std::vector, no shared workspace
 // aliasing) but each pass is written to reproduce the reference's tie-breaking exactly.
 #include "sf_symbolic.h"
+#include <atomic>
 #include <thread>
 #include <time.h>
 #include <cstdio>
@@ -695,14 +696,24 @@ int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, cons
 // of at most `leaf` vertices are ordered by BFS (reverse Cuthill-McKee like), which keeps their fill banded.
 // ---------------------------------------------------------------------------------------------
 namespace {
+// The dissection of two pieces is independent: they own disjoint vertices and -- because a piece's vertices are ordered A, then B,
+// then the separator -- disjoint, known ranges of the output.  So every call carries its output offset, piece ids come from one
+// atomic counter, and a big enough first half is dissected by another host thread (at most analysis_threads() at a time) while the
+// caller does the second: same permutation as the sequential code, whatever the thread count.  mark[] is read across pieces (a
+// neighbour in another piece) while its owner may be renumbering it: those accesses are relaxed atomics, and the only thing a
+// reader asks is "is it MY id", which no other piece's id ever equals.
 struct NdCtx {
     const std::vector<Long>& Ap;
     const std::vector<Long>& Ai;
     std::vector<Long> mark;      // mark[v] = id of the piece v currently belongs to
     std::vector<Long> level;
     Long* out;
-    Long pos = 0;
     Long leaf;
+    std::atomic<Long> next_id{1};
+    std::atomic<int> helpers{0};
+    int max_helpers = 0;
+    Long mk(Long v) const { return __atomic_load_n(&mark[v], __ATOMIC_RELAXED); }
+    void set_mk(Long v, Long id) { __atomic_store_n(&mark[v], id, __ATOMIC_RELAXED); }
 };
 
 // BFS inside piece `id` from `root`; returns the vertices in BFS order and fills level[]
@@ -710,47 +721,48 @@ void nd_bfs(NdCtx& c, Long id, Long root, std::vector<Long>& order) {
     order.clear();
     order.push_back(root);
     c.level[root] = 0;
-    // visited flag: reuse level with a generation trick -> use a local set via negative ids is overkill; mark with -2-id
-    c.mark[root] = -2 - id;
+    c.set_mk(root, -2 - id);        // visited: -2 - id (unique to the piece as well)
     for (size_t h = 0; h < order.size(); ++h) {
         const Long v = order[h];
         for (Long p = c.Ap[v]; p < c.Ap[v + 1]; ++p) {
             const Long w = c.Ai[p];
-            if (c.mark[w] == id) {
-                c.mark[w] = -2 - id;
+            if (c.mk(w) == id) {
+                c.set_mk(w, -2 - id);
                 c.level[w] = c.level[v] + 1;
                 order.push_back(w);
             }
         }
     }
-    for (Long v : order) c.mark[v] = id;    // restore
+    for (Long v : order) c.set_mk(v, id);    // restore
 }
 
-void nd_component(NdCtx& c, std::vector<Long>& comp, Long& next_id);
+void nd_component(NdCtx& c, std::vector<Long>& comp, Long pos);
 
-// `verts`: vertices carrying one common mark.  Its connected components are peeled off one after the other
-// (iteratively: a diagonal matrix has n components) and dissected.
-void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long& next_id) {
-    const Long id = c.mark[verts[0]];
+// `verts`: vertices carrying one common mark, to be written to out[pos ..).  Its connected components are peeled off one after
+// the other (iteratively: a diagonal matrix has n components) and dissected.
+void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos) {
+    const Long id = c.mk(verts[0]);
     std::vector<Long> comp;
     for (Long v : verts) {
-        if (c.mark[v] != id) continue;          // already ordered as part of an earlier component
+        if (c.mk(v) != id) continue;          // already ordered as part of an earlier component
         nd_bfs(c, id, v, comp);
-        const Long cid = next_id++;
-        for (Long w : comp) c.mark[w] = cid;
-        nd_component(c, comp, next_id);
+        const Long cid = c.next_id++;
+        for (Long w : comp) c.set_mk(w, cid);
+        const Long sz = (Long)comp.size();
+        nd_component(c, comp, pos);
+        pos += sz;
     }
 }
 
-// one connected piece, all vertices marked with one id; `comp` is in BFS order from some vertex of it
-void nd_component(NdCtx& c, std::vector<Long>& comp, Long& next_id) {
+// one connected piece, all vertices marked with one id; `comp` is in BFS order from some vertex of it; output range out[pos, pos + |comp|)
+void nd_component(NdCtx& c, std::vector<Long>& comp, Long pos) {
     std::vector<Long>& verts = comp;
-    const Long id = c.mark[verts[0]];
+    const Long id = c.mk(verts[0]);
     if ((Long)verts.size() <= c.leaf) {
         // BFS order from a pseudo-peripheral vertex, reversed
         std::vector<Long> o2;
         nd_bfs(c, id, comp.back(), o2);
-        for (size_t k = o2.size(); k-- > 0;) { c.out[c.pos++] = o2[k]; c.mark[o2[k]] = -1; }
+        for (size_t k = o2.size(); k-- > 0;) { c.out[pos++] = o2[k]; c.set_mk(o2[k], -1); }
         return;
     }
     // pseudo-peripheral root: restart the BFS from the last vertex of the previous one
@@ -758,7 +770,7 @@ void nd_component(NdCtx& c, std::vector<Long>& comp, Long& next_id) {
     nd_bfs(c, id, comp.back(), order);
     const Long nlev = c.level[order.back()] + 1;
     if (nlev < 3) {     // (nearly) complete graph: no useful separator
-        for (size_t k = order.size(); k-- > 0;) { c.out[c.pos++] = order[k]; c.mark[order[k]] = -1; }
+        for (size_t k = order.size(); k-- > 0;) { c.out[pos++] = order[k]; c.set_mk(order[k], -1); }
         return;
     }
     std::vector<Long> cnt(nlev, 0);
@@ -773,16 +785,26 @@ void nd_component(NdCtx& c, std::vector<Long>& comp, Long& next_id) {
         below += cnt[l];
     }
     std::vector<Long> A, B, Sep;
-    const Long ida = next_id++, idb = next_id++;
+    const Long ida = c.next_id++, idb = c.next_id++;
     for (Long v : order) {
-        if (c.level[v] < best) { A.push_back(v); c.mark[v] = ida; }
-        else if (c.level[v] > best) { B.push_back(v); c.mark[v] = idb; }
+        if (c.level[v] < best) { A.push_back(v); c.set_mk(v, ida); }
+        else if (c.level[v] > best) { B.push_back(v); c.set_mk(v, idb); }
         else Sep.push_back(v);
     }
-    for (Long v : Sep) c.mark[v] = -1;       // removed from the graph for the recursion
-    if (!A.empty()) nd_recurse(c, A, next_id);
-    if (!B.empty()) nd_recurse(c, B, next_id);
-    for (Long v : Sep) c.out[c.pos++] = v;
+    for (Long v : Sep) c.set_mk(v, -1);       // removed from the graph for the recursion
+    { std::vector<Long>().swap(order); std::vector<Long>().swap(comp); }
+    const Long posA = pos, posB = pos + (Long)A.size(), posS = posB + (Long)B.size();
+    std::thread helper;
+    if (!A.empty() && !B.empty() && (Long)A.size() >= 20000 && c.helpers.fetch_add(1) < c.max_helpers)
+        helper = std::thread([&c, &A, posA] { nd_recurse(c, A, posA); });
+    else {
+        if (!A.empty() && !B.empty() && (Long)A.size() >= 20000) c.helpers.fetch_sub(1);      // no free helper: undo the claim
+        if (!A.empty()) nd_recurse(c, A, posA);
+    }
+    if (!B.empty()) nd_recurse(c, B, posB);
+    if (helper.joinable()) { helper.join(); c.helpers.fetch_sub(1); }
+    Long q = posS;
+    for (Long v : Sep) c.out[q++] = v;
 }
 }  // namespace
 
@@ -806,13 +828,15 @@ int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm)
                 if (i != j) { Ai[fill[i]++] = j; Ai[fill[j]++] = i; }
             }
     }
-    NdCtx c{Ap, Ai, std::vector<Long>(n, 0), std::vector<Long>(n, 0), perm, 0, leaf};
+    NdCtx c{Ap, Ai, std::vector<Long>(n, 0), std::vector<Long>(n, 0), perm, leaf};
+    c.max_helpers = analysis_threads() - 1;
     if (n == 0) return 0;
     std::vector<Long> all(n);
     for (Long v = 0; v < n; ++v) all[v] = v;
-    Long next_id = 1;
-    nd_recurse(c, all, next_id);    // recursion depth = dissection depth, O(log n) for balanced level separators
-    if (c.pos != n) return 2;
+    for (Long v = 0; v < n; ++v) perm[v] = -1;
+    nd_recurse(c, all, 0);    // recursion depth = dissection depth, O(log n) for balanced level separators
+    for (Long v = 0; v < n; ++v)
+        if (perm[v] < 0) return 2;
     return 0;
 }
 

@@ -91,7 +91,8 @@ def test_bad_inputs_are_rejected():
 
 def test_threaded_analysis_is_bit_identical_to_sequential(tmp_path):
     """the triangles of P A P^T are built by parallel stable bucket sorts (SF_ANALYZE_THREADS, read once per process): every
-    integer and value array must be identical to the one-thread result (and therefore to the reference's sequential fill,
+    integer and value array -- and the built-in nested-dissection ordering, whose two halves are dissected by different threads --
+    must be identical to the one-thread result (and therefore to the reference's sequential fill,
     which the oracle comparisons above pin).  Two child processes, 1 and 8 threads, Cholesky and unsymmetric LU."""
     import hashlib, json, os, subprocess, sys
     code = r'''
@@ -109,6 +110,9 @@ n, Cp, Ci, Cx = sf.gen.unsymmetric_stencil(g, g, g, seed=4)
 S = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g), 1 << 30, "lu", False)
 for k in ("Lp", "Li", "LTi", "Up", "Ui", "UTp", "UTi", "Super", "Lsi", "Lx", "Ux", "UTx"):
     out["lu." + k] = hashlib.sha256(getattr(S, k).tobytes()).hexdigest()
+g = 46
+n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
+out["graph_nd_perm"] = hashlib.sha256(sf.graph_nd_perm(n, Cp, Ci).tobytes()).hexdigest()
 print(json.dumps(out))
 '''
     res = []
