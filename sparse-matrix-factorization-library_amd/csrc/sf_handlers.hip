@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "sf_kernels.h"
 #include "sf_plan_internal.h"
 #include "sf_symbolic.h"
 
@@ -229,6 +230,18 @@ int sf_handlers_allocate(struct common_info_struct* common, struct gpu_info_stru
         (*list)[d].devMemSize = prop.totalGlobalMem;
         (*list)[d].st = new (std::nothrow) HandlerState();
         min_mem = std::min(min_mem, (size_t)prop.totalGlobalMem);
+        // pay the per-process, per-device one-time costs here (the reference creates its streams and cuBLAS / cuSOLVER handles in
+        // this call, C:92-283) instead of inside the first SparseFrame_factorize: runtime and code-object initialisation, the first
+        // device and pinned allocations
+        if (d == phys && hipSetDevice(phys) == hipSuccess) {
+            void* dp = nullptr;
+            void* hp = nullptr;
+            if (hipMalloc(&dp, 1 << 20) == hipSuccess) (void)hipFree(dp);
+            if (hipHostMalloc(&hp, 1 << 20, hipHostMallocDefault) == hipSuccess) (void)hipHostFree(hp);
+            sf::launch_noop(nullptr);
+            (void)hipDeviceSynchronize();
+            (void)hipGetLastError();
+        }
     }
     if (ndev > 0 && (*list)[0].st) (*list)[0].st->multi = new (std::nothrow) MultiState();
     if (ndev > 0 && min_mem != (size_t)-1) {

@@ -164,6 +164,8 @@ void launch_solve_fwd(const SolveTask* t, int nt, int big, const double* Lsx, co
 void launch_solve_bwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
                       hipStream_t st);
 
+void launch_noop(hipStream_t st);
+
 // device twin of SparseFrame_validate's residual (C:3182-3263): b_i = 1 + i/n is written to b, r = A x - b, the four maxima
 // |r|_inf, |A|_1, |x|_inf, |b|_inf to norms[0..3] (zero them first).  Up == nullptr: (Lp, Li, Lx) is one triangle used symmetrically.
 void launch_residual(const int64_t* Lp, const int32_t* Li, const double* Lx, const int64_t* Up, const int32_t* Ui, const double* Ux,

@@ -1736,6 +1736,10 @@ k_resid_norms(int32_t n, const double* __restrict__ r, const double* __restrict_
     }
 }
 
+__global__ void k_noop() {}
+// one empty launch: loads this library's code object onto the current device (the first launch of a process pays for that)
+void launch_noop(hipStream_t st) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st); }
+
 void launch_residual(const int64_t* Lp, const int32_t* Li, const double* Lx, const int64_t* Up, const int32_t* Ui, const double* Ux,
                      int32_t n, const double* x, double* r, double* colsum, double* b, double* norms, hipStream_t st) {
     if (n <= 0) return;
