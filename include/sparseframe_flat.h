@@ -282,6 +282,12 @@ int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_inf
  * host copy (three windows of 512 values) still equals the device's; otherwise returns SF_ERR_ARG and the caller solves on the host
  * as the reference does (C:3036-3139).  SF_SOLVE=host in the environment forces the host solve.  forget: the host copy is being freed. */
 int sf_handlers_solve_resident(const sf_float *Lsx_host, const sf_float *b, sf_float *x);
+/* the same with the symbolic arrays of the matrix at hand: after a factorization by SEVERAL handlers the factor is spread over
+ * their plans; with these arrays the library can build a whole plan on the first handler's device, gather the panels into it
+ * (device to device) and solve there -- when one device has room for the whole factor; otherwise SF_ERR_ARG (host solve) */
+int sf_handlers_solve_resident_sym(const sf_float *Lsx_host, const sf_float *b, sf_float *x, int lu, sf_long n, sf_long nsuper,
+                                   const sf_long *Super, const sf_long *SuperMap, const sf_long *Lsip, const sf_long *Lsi,
+                                   const sf_long *Lsxp, const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui);
 void sf_handlers_forget(const sf_float *Lsx_host);
 int64_t sf_handlers_resident_solves(void);     /* how many solves were served from a resident factor so far (tests) */
 

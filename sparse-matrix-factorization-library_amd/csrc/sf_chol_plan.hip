@@ -1175,6 +1175,53 @@ int sf_chol_plan_factorize_segment(sf_chol_plan* p, sf_long k, int sync) {
 
 }  // extern "C"
 
+// Gathers a factor that is distributed over the plans of several ranks (sharded / mapped plans of ONE pattern, factorized and
+// synchronised) into a whole plan of that pattern: every panel from the first part that stores it (a shared top panel is complete
+// on every rank of its group once its chain has run), device to device over xGMI (hipMemcpyPeerAsync), LU: both panels and the
+// pivot records.  After it `dst` solves as if it had factorized itself.  Used by the struct path's solve after a multi-handler
+// factorization (sf_handlers.hip).
+int sf_plan_import_from(sf_chol_plan* dst, sf_chol_plan* const* parts, int nparts) {
+    if (!dst || dst->partial || !parts || nparts < 1) return SF_ERR_ARG;
+    for (int r = 0; r < nparts; ++r) {
+        const sf_chol_plan* P = parts[r];
+        if (!P || P->n != dst->n || P->nsuper != dst->nsuper || P->lu != dst->lu) return SF_ERR_ARG;
+        HIP_TRY(hipSetDevice(P->device));
+        HIP_TRY(hipStreamSynchronize(P->stream));
+    }
+    HIP_TRY(hipSetDevice(dst->device));
+    sf_long s = 0;
+    while (s < dst->nsuper) {
+        int src = -1;
+        for (int r = 0; r < nparts && src < 0; ++r)
+            if (parts[r]->h_XP[s] >= 0) src = r;
+        if (src < 0) return SF_ERR_ARG;                 // a panel nobody stores
+        const sf_chol_plan* P = parts[src];
+        sf_long e = s;
+        int64_t len = 0;
+        while (e < dst->nsuper && P->h_XP[e] >= 0 && P->h_XP[e] == P->h_XP[s] + len && dst->h_XP[e] == dst->h_XP[s] + len) {
+            bool earlier = false;                       // keep "the first part that stores it" for every panel of the run
+            for (int r = 0; r < src; ++r) earlier = earlier || parts[r]->h_XP[e] >= 0;
+            if (earlier) break;
+            len += (dst->h_Super[e + 1] - dst->h_Super[e]) * (dst->h_Lsip[e + 1] - dst->h_Lsip[e]);
+            ++e;
+        }
+        if (e == s) return SF_ERR_ARG;
+        HIP_TRY(hipMemcpyPeerAsync(dst->d_Lsx + dst->h_XP[s], dst->device, P->d_Lsx + P->h_XP[s], P->device, len * sizeof(double), dst->stream));
+        if (dst->lu) {
+            HIP_TRY(hipMemcpyPeerAsync(dst->d_Lsx + dst->xC + dst->h_XP[s], dst->device, P->d_Lsx + P->xC + P->h_XP[s], P->device,
+                                       len * sizeof(double), dst->stream));
+            if (dst->d_piv && P->d_piv)
+                HIP_TRY(hipMemcpyPeerAsync(dst->d_piv + dst->h_Super[s], dst->device, P->d_piv + dst->h_Super[s], P->device,
+                                           (size_t)(dst->h_Super[e] - dst->h_Super[s]) * sizeof(int32_t), dst->stream));
+        }
+        s = e;
+    }
+    dst->piv_tol = parts[0]->piv_tol;
+    dst->piv_perturb = parts[0]->piv_perturb;
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    return SF_OK;
+}
+
 // The pieces of the pipelined driver (sf_multi.hip).  Segment k's sum uses half k & 1 of the scratch buffer and the plan's second
 // stream:  begin (everything the sum needs has been enqueued on the main stream) -> pack on the second stream, returns the buffer for
 // the collective, which the caller issues on sf_plan_stream2 -> reduced (marks the collective's end on the second stream) ->

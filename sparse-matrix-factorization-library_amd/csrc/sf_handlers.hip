@@ -11,8 +11,11 @@
 #include <sparseframe_hip.h>
 
 #include <chrono>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -75,15 +78,33 @@ PlanKey make_key(int lu, sf_long n, sf_long nsuper, const sf_long* Super, const 
 }
 
 struct HandlerState;
-// host copies of factors that a single handler's cached plan still holds on the device (sf_handlers_solve_resident)
-struct Resident { sf_chol_plan* plan; int epoch; HandlerState* st; };
+// whole plan a distributed factor is gathered into for the struct path's solve (owned by a MultiState cache entry and by the
+// registry entries that point at it)
+struct SolverSlot {
+    sf_chol_plan* plan = nullptr;
+    std::vector<int> imported;          // epochs of the parts the plan currently holds
+    ~SolverSlot() { if (plan) sf_chol_plan_destroy(plan); }
+};
+// host copies of factors that are still on the device(s): in a single handler's cached plan (plan), or distributed over the
+// per-rank plans of a multi-handler factorization (parts), see sf_handlers_solve_resident
+struct Resident {
+    sf_chol_plan* plan = nullptr;
+    int epoch = 0;
+    std::vector<sf_chol_plan*> parts;
+    std::vector<int> part_epochs;
+    std::shared_ptr<SolverSlot> slot;
+    int device = 0;
+};
 std::mutex g_res_mu;
 std::unordered_map<const void*, Resident> g_resident;
 int64_t g_resident_solves = 0;      // solves served from a resident factor (tests)
 void forget_plan(sf_chol_plan* plan) {
     std::lock_guard<std::mutex> g(g_res_mu);
-    for (auto it = g_resident.begin(); it != g_resident.end();)
-        if (it->second.plan == plan) it = g_resident.erase(it); else ++it;
+    for (auto it = g_resident.begin(); it != g_resident.end();) {
+        bool hit = it->second.plan == plan;
+        for (sf_chol_plan* q : it->second.parts) hit = hit || q == plan;
+        if (hit) it = g_resident.erase(it); else ++it;
+    }
 }
 void destroy_plan(sf_chol_plan* plan) {
     if (!plan) return;
@@ -96,13 +117,13 @@ void destroy_plan(sf_chol_plan* plan) {
 struct MultiState {
     std::mutex mu;
     std::vector<sf_comm*> comms;
-    struct Entry { PlanKey key; std::vector<sf_chol_plan*> plans; uint64_t stamp; };
+    struct Entry { PlanKey key; std::vector<sf_chol_plan*> plans; uint64_t stamp; std::shared_ptr<SolverSlot> slot; };
     std::vector<Entry> cache;
     uint64_t clock = 0;
     uint64_t builds = 0;        // sets of per-rank plans built (cache misses)
     ~MultiState() {
         for (Entry& e : cache)
-            for (sf_chol_plan* p : e.plans) sf_chol_plan_destroy(p);
+            for (sf_chol_plan* p : e.plans) destroy_plan(p);
         for (sf_comm* c : comms) sf_comm_destroy(c);
     }
 };
@@ -158,13 +179,13 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
             size_t lru = 0;
             for (size_t i = 1; i < M.cache.size(); ++i)
                 if (M.cache[i].stamp < M.cache[lru].stamp) lru = i;
-            for (sf_chol_plan* p : M.cache[lru].plans) sf_chol_plan_destroy(p);
+            for (sf_chol_plan* p : M.cache[lru].plans) destroy_plan(p);
             M.cache.erase(M.cache.begin() + lru);
         }
         owner.assign(nsuper, 0);
         // cost of a top flop relative to a subtree flop: its 1/N share plus the replicated chain and the all-reduce
         if (sf::subtree_partition(nsuper, Super, SuperMap, Lsip, Lsi, N, owner.data(), nullptr, nullptr, 1.0 / N + 0.25)) return SF_ERR_ARG;
-        M.cache.push_back(MultiState::Entry{key, std::vector<sf_chol_plan*>(N, nullptr), ++M.clock});
+        M.cache.push_back(MultiState::Entry{key, std::vector<sf_chol_plan*>(N, nullptr), ++M.clock, std::make_shared<SolverSlot>()});
         entry = &M.cache.back();
         ++M.builds;
     }
@@ -188,10 +209,11 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
     th.clear();
     for (int r = 0; r < N; ++r)
         if (rcs[r]) {
-            for (sf_chol_plan*& p : entry->plans) { sf_chol_plan_destroy(p); p = nullptr; }
-            M.cache.pop_back();
+            for (sf_chol_plan*& p : entry->plans) { destroy_plan(p); p = nullptr; }
+            M.cache.erase(M.cache.begin() + (entry - M.cache.data()));
             return rcs[r];
         }
+    for (int r = 0; r < N; ++r) forget_plan(entry->plans[r]);       // the host copies these plans' factors stood for are history
     for (int r = 0; r < N; ++r)
         th.emplace_back([&, r] { rcs[r] = sf_chol_plan_factorize_distributed(entry->plans[r], M.comms[r], Lsx_out, 1); });
     for (std::thread& t : th) t.join();
@@ -200,6 +222,17 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
     if (lu && PivOut)      // every rank reports the blocks of the panels it stores (the top panels' records agree on all ranks)
         for (int r = 0; r < N; ++r)
             if (int rc = sf_lu_plan_get_pivots(entry->plans[r], PivOut)) return rc;
+    {
+        // the factor is now spread over the ranks' plans; a solve of the struct path may gather it into a whole plan on the first
+        // handler's device (sf_handlers_solve_resident)
+        Resident R;
+        R.parts = entry->plans;
+        for (sf_chol_plan* q : entry->plans) R.part_epochs.push_back(q->epoch);
+        R.slot = entry->slot;
+        R.device = list[0].gpuIndex_physical;
+        std::lock_guard<std::mutex> g(g_res_mu);
+        g_resident[(const void*)Lsx_out] = std::move(R);
+    }
     return SF_OK;
 }
 
@@ -347,8 +380,11 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
     int rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
     if (!rc && lu && PivOut) rc = sf_lu_plan_get_pivots(plan, PivOut);
     if (!rc) {
+        Resident R;
+        R.plan = plan;
+        R.epoch = plan->epoch;
         std::lock_guard<std::mutex> g(g_res_mu);
-        g_resident[(const void*)Lsx_out] = Resident{plan, plan->epoch, H.st};
+        g_resident[(const void*)Lsx_out] = std::move(R);
     }
     if (trace) {
         const auto tk3 = std::chrono::steady_clock::now();
@@ -362,29 +398,78 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
 // SparseFrame_solve_supernodal's fast path: see sparseframe_flat.h.  g_res_mu is held for the whole solve: a factorization or a
 // destruction of the same plan waits in forget_plan until it is over (lock order there: handler lock, then g_res_mu; here only
 // g_res_mu), so nobody else touches the plan meanwhile.
-int sf_handlers_solve_resident(const sf_float* Lsx_host, const sf_float* b, sf_float* x) {
+int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, sf_float* x, int lu, sf_long n, sf_long nsuper,
+                                   const sf_long* Super, const sf_long* SuperMap, const sf_long* Lsip, const sf_long* Lsi,
+                                   const sf_long* Lsxp, const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui) {
     if (!Lsx_host || !b || !x) return SF_ERR_ARG;
+    const bool trace = getenv("SF_TRACE") != nullptr;
+    auto why = [&](const char* m) { if (trace) fprintf(stderr, "[sparseframe-hip] resident solve not used: %s\n", m); return SF_ERR_ARG; };
     if (const char* e = getenv("SF_SOLVE"))
         if (!strcmp(e, "host")) return SF_ERR_ARG;
     std::lock_guard<std::mutex> g(g_res_mu);
     auto it = g_resident.find((const void*)Lsx_host);
-    if (it == g_resident.end()) return SF_ERR_ARG;
-    sf_chol_plan* plan = it->second.plan;
-    if (plan->epoch != it->second.epoch || plan->partial) { g_resident.erase(it); return SF_ERR_ARG; }
+    if (it == g_resident.end()) return why("no resident factor is registered for this Lsx");
+    Resident& R = it->second;
+    sf_chol_plan* plan = R.plan;
+    if (!R.parts.empty()) {
+        // distributed factor: gather it (once per factorization) into a whole plan on the first handler's device -- panels travel
+        // device to device, the solve then runs there.  Needs the symbolic arrays (to build that plan) and room for the whole
+        // factor on one device; otherwise the caller solves on the host.
+        for (size_t r = 0; r < R.parts.size(); ++r)
+            if (R.parts[r]->epoch != R.part_epochs[r]) { g_resident.erase(it); return why("a rank's plan holds a later factorization"); }
+        SolverSlot& S = *R.slot;
+        if (!S.plan) {
+            if (!Super || !SuperMap || !Lsip || !Lsi || !Lsxp || !Lp || !Li || nsuper <= 0) return why("distributed factor and no symbolic arrays");
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(R.device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return why("hipMemGetInfo failed");
+            const double need = (double)Lsxp[nsuper] * 8.0 * (lu ? 2.0 : 1.0) * 1.15 + 2e9;
+            if ((double)free_b < need) return why("the first handler's device has no room for the whole factor");
+            const int rc = lu ? sf_lu_plan_create(&S.plan, R.device, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui)
+                              : sf_chol_plan_create(&S.plan, R.device, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li);
+            if (rc) { S.plan = nullptr; (void)hipGetLastError(); return why("the whole plan could not be built"); }
+            S.imported.clear();
+        }
+        if (S.imported != R.part_epochs) {
+            if (sf_plan_import_from(S.plan, R.parts.data(), (int)R.parts.size()) != SF_OK) { S.imported.clear(); return why("gathering the panels failed"); }
+            S.imported = R.part_epochs;
+        }
+        plan = S.plan;
+    } else if (plan->epoch != R.epoch || plan->partial) {
+        g_resident.erase(it);
+        return why("the plan holds a later factorization");
+    }
     // the host copy must still be what the device holds (it came from there bit by bit): three windows of 512 values
     const sf_long xs = plan->xsize, w = std::min<sf_long>(512, xs);
     const sf_long starts[3] = {0, std::max<sf_long>(0, xs / 2 - w / 2), xs - w};
     std::vector<double> dev((size_t)w);
+    // (a gathered factor: the ranks of a group hold copies of a shared panel that differ in the last bits -- each ran the chain with
+    // its own order of atomic additions -- and the host piece may come from another rank than the gathered one: compare to 1e-10)
+    const bool exact = R.parts.empty();
     for (sf_long st : starts) {
-        if (sf_chol_plan_get_factor_range(plan, st, st + w, dev.data()) != SF_OK ||
-            memcmp(dev.data(), Lsx_host + st, (size_t)w * sizeof(double)) != 0) {
+        bool same = sf_chol_plan_get_factor_range(plan, st, st + w, dev.data()) == SF_OK;
+        if (same && exact) same = memcmp(dev.data(), Lsx_host + st, (size_t)w * sizeof(double)) == 0;
+        if (same && !exact) {
+            double amax = 0.0, dmax = 0.0;
+            for (sf_long i = 0; i < w; ++i) {
+                const double h = Lsx_host[st + i], d = dev[(size_t)i];
+                if (!(h == h) || !(d == d)) continue;          // entries the layout does not define (never written) may be anything
+                amax = std::max(amax, std::fabs(h));
+                dmax = std::max(dmax, std::fabs(h - d));
+            }
+            same = dmax <= 1e-10 * amax;
+        }
+        if (!same) {
             g_resident.erase(it);
-            return SF_ERR_ARG;
+            return why("the host copy differs from the device's (sampled)");
         }
     }
     const int rc = plan->lu ? sf_lu_plan_solve(plan, b, x) : sf_chol_plan_solve(plan, b, x);
     if (!rc) ++g_resident_solves;
     return rc;
+}
+
+int sf_handlers_solve_resident(const sf_float* Lsx_host, const sf_float* b, sf_float* x) {
+    return sf_handlers_solve_resident_sym(Lsx_host, b, x, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 int64_t sf_handlers_resident_solves(void) {

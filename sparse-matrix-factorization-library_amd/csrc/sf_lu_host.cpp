@@ -250,7 +250,8 @@ int SparseFrame_solve_supernodal(struct matrix_info_struct* mi) {
     // the factor SparseFrame_factorize copied into Lsx is normally still resident in the handler's plan: solve there (two sweeps
     // over the factor in HBM instead of host memory).  Falls through to the reference's host solve when it is not (several
     // handlers, plan evicted or re-used, Lsx changed by the caller, SF_SOLVE=host).
-    if (sf_handlers_solve_resident(mi->Lsx, mi->Bx, mi->Xx) == SF_OK) {
+    if (sf_handlers_solve_resident_sym(mi->Lsx, mi->Bx, mi->Xx, 1, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi,
+                                       mi->Lsxp, mi->Lp, mi->Li, mi->isSymmetric ? nullptr : mi->Up, mi->isSymmetric ? nullptr : mi->Ui) == SF_OK) {
         mi->solveTime = wall_seconds() - t0;
         return 0;
     }

@@ -206,6 +206,8 @@ struct sf_chol_plan {
 // sf_dl_end publishes what is left, waits for the workers and returns SF_OK or the first error.
 int sf_dl_begin(sf_chol_plan* p, double* host_out);
 int sf_dl_end(sf_chol_plan* p);
+// gathers the panels of the parts (plans of several ranks, one pattern) into the whole plan dst (sf_chol_plan.hip)
+int sf_plan_import_from(sf_chol_plan* dst, sf_chol_plan* const* parts, int nparts);
 // pipelined segment sums (sf_chol_plan.hip), used by sf_chol_plan_factorize_distributed
 int sf_seg_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count);
 void* sf_plan_stream2(sf_chol_plan* p);
