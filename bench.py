@@ -36,6 +36,27 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix; v_mfma_f64_16x16x
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (guide: 8 TB/s spec, ~6.3 TB/s achievable)
 
 
+def config1_case(sf, np):
+    """BASELINE config 1 -- the 2-D 5-point Laplacian 100 x 100 through the reference's own stage functions, as its demo runs it
+    (SparseFrame_analyze with the default ordering, SparseFrame_factorize on the GPU, SparseFrame_validate = solve + residual):
+    plumbing, not performance; the times of the second call (cached plan)"""
+    n, Cp, Ci, Cx = sf.gen.laplacian_lower(100, 100)
+    common = sf.CommonInfo()
+    out = {"workload": "2D 5-point Laplacian 100x100 through the struct entry points (SparseFrame_analyze / _factorize / _validate), "
+                       "built-in nested-dissection ordering", "n": n}
+    for call in range(2):
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx)
+        mi.analyze(common)
+        mi.factorize(common)
+        res = mi.validate()
+        out.update({"analyze_ms": round(1e3 * mi.c.analyzeTime, 3), "factorize_ms": round(1e3 * mi.c.factorizeTime, 3),
+                    "solve_ms": round(1e3 * mi.c.solveTime, 3), "residual": res, "nsuper": int(mi.c.nsuper)})
+        mi.cleanup()
+    common.close()
+    return out
+
+
 def secondary_case(sf, np, kind, steps=3):
     """one more BASELINE config timed in the same run (driver-side numbers for configs 3 and 5):
     kind 'config3' = 2-D 1000x1000 21-point random SPD stencil (the HBM-/latency-bound extend-add config),
@@ -360,7 +381,7 @@ def main():
             st.append(mi.c.factorizeTime * 1e3)
         pc.update({"struct_first_call_ms": round(st[0], 1), "struct_second_call_ms": round(st[1], 1),
                    "struct_second_call_over_resident_step": round(st[1] / ms_per_step, 3),
-                   "struct_residual": mi.validate() if n <= 300000 else None,
+                   "struct_residual": mi.validate(), "struct_solve_ms": round(1e3 * mi.c.solveTime, 3),      # the solve finds the factor resident in the handler's plan
                    "note": "SparseFrame_factorize(common, gpu_info_list, matrix_info): pageable Lsx malloc'ed by SparseFrame_analyze; "
                            "call 1 = plan build + first touch of Lsx + factorize + overlapped copy-back, call 2 = cached plan"})
         mi.cleanup()
@@ -382,7 +403,8 @@ def main():
         del Lsx
 
     if rank == 0 and ngpu == 1 and not args.no_secondary and not lu and args.workload == "lap3d" and args.grid in (0, 128):
-        out["secondary"] = {"config3": secondary_case(sf, np, "config3"), "config5": secondary_case(sf, np, "config5")}
+        out["secondary"] = {"config1": config1_case(sf, np), "config3": secondary_case(sf, np, "config3"),
+                            "config5": secondary_case(sf, np, "config5")}
 
     if rank == 0 and ngpu == 1 and args.cpu_grid > 0:
         import oracle
