@@ -105,7 +105,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                        const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
                        const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1,
-                       const uint32_t* top_mask = nullptr) {
+                       const uint32_t* top_mask = nullptr, const double* root_cum = nullptr) {
+    // root_cum (optional, nranks + 1 values from 0 to 1): the shares of the split launches of the sets that ALL ranks take part in
+    // are [root_cum[r], root_cum[r + 1]) instead of equal ones -- create_mapped uses them to even out ranks whose other groups
+    // differ in weight (an elimination tree the amalgamation made lopsided)
     // top_mask[s] (phase-1 supernodes, optional): bit r set = rank r takes part in supernode s (proportional mapping: the
     // ranks whose subtrees lie below s).  Its panel exists only on those ranks, their GEMM shares and the all-reduce run
     // inside that group.  Without it every rank takes part in every top supernode.
@@ -286,7 +289,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // The sweep: one set of independent supernodes at a time -- phase 0: a level of the owned subtrees; phase 1: the top
     // supernodes of one level that share one group of ranks (ascending mask: every rank meets the sets it shares with
     // another rank in the same order, so the groups' collectives cannot wait for each other in a circle).
-    struct LevelSet { int ph; std::vector<sf_long> sn; uint32_t mask; int share_idx, share_cnt; };
+    struct LevelSet { int ph; std::vector<sf_long> sn; uint32_t mask; int share_idx, share_cnt; double lo = 0.0, hi = 1.0; };
     std::vector<LevelSet> sets;
     for (int ph = 0; ph < 2; ++ph) {
         std::vector<std::vector<sf_long>> by_level(nlevels);
@@ -301,6 +304,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             ms.erase(std::unique(ms.begin(), ms.end()), ms.end());
             for (uint32_t m : ms) {
                 LevelSet LS{1, {}, m, group_idx(m), __builtin_popcount(m)};
+                LS.lo = (double)LS.share_idx / LS.share_cnt;
+                LS.hi = (double)(LS.share_idx + 1) / LS.share_cnt;
+                if (root_cum && LS.share_cnt == nranks && nranks > 1) { LS.lo = root_cum[rank]; LS.hi = root_cum[rank + 1]; }
                 for (sf_long s : by_level[l])
                     if (gmask[s] == m) LS.sn.push_back(s);
                 sets.push_back(std::move(LS));
@@ -352,6 +358,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
                 p->launches.back().split = split && LS.share_cnt > 1;
                 p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
+                p->launches.back().share_lo = LS.lo; p->launches.back().share_hi = LS.hi;
             }
         };
         // Look-ahead for shared panels (several ranks): the update of block jo is cut into the FAR part (columns of the blocks
@@ -551,11 +558,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             p->launches.push_back(Launch{3, g0, (int)(gtasks.size() - g0)});
             p->launches.back().split = shared && LS.share_cnt > 1;
             p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
+                p->launches.back().share_lo = LS.lo; p->launches.back().share_hi = LS.hi;
         }
         if ((int64_t)stasks.size() > s0) {
             p->launches.push_back(Launch{6, s0, (int)(stasks.size() - s0)});
             p->launches.back().split = shared && LS.share_cnt > 1;
             p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
+                p->launches.back().share_lo = LS.lo; p->launches.back().share_hi = LS.hi;
             p->launches.back().flops = level_small_flops;
         }
     }
@@ -891,7 +900,63 @@ static int create_mapped(sf_chol_plan** out, int device, bool lu, sf_long n, sf_
         if (owner[s] >= 0) { phase[s] = owner[s] == rank ? 0 : -1; mask[s] = 0; }
         else phase[s] = ((mask[s] >> rank) & 1u) ? 1 : -1;
     }
-    return plan_create(out, device, lu, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, phase.data(), 2, rank, nranks, mask.data());
+    // Weighted shares of the sets every rank takes part in (the root's GEMMs: the largest pool of divisible work).  The relaxed
+    // amalgamation can make the tree lopsided -- at 161^3 over 4 ranks one pair of ranks shares a 14,641-column separator, the other
+    // pair a 6,720-column one -- so the ranks arrive at the root with different loads.  Model (every rank evaluates the same
+    // numbers): time of a rank before the root = its subtrees' flops at 42 TFLOP/s + for each smaller group it belongs to the
+    // replicated part (chains: 45 us per 64 columns; in-block and near-part updates) + its equal share of that group's divisible
+    // flops at 48 TFLOP/s (calibrated on tools/emulate_rank.py, 128^3 / 8 and 161^3 / 4); the root's divisible flops, at 58 TFLOP/s, are
+    // then dealt out so that the ranks finish together (shares clamped to [0.2, 3] / nranks).  SF_WEIGHTED_SHARES=0: equal shares.
+    std::vector<double> cum;
+    const char* wenv = getenv("SF_WEIGHTED_SHARES");
+    if (nranks > 1 && !(wenv && atoi(wenv) == 0)) {
+        const uint32_t all = nranks >= 32 ? 0xffffffffu : ((1u << nranks) - 1u);
+        std::vector<double> before(nranks, 0.0);
+        double root_ms = 0.0;
+        for (sf_long s = 0; s < nsuper; ++s) {
+            const double k = (double)(Super[s + 1] - Super[s]), r = (double)(Lsip[s + 1] - Lsip[s]), m = r - k;
+            double f = k * k * k / 3.0 + m * k * k;
+            {
+                const sf_long* rows = Lsi + Lsip[s];
+                sf_long i = (sf_long)k;
+                const sf_long nsrow = (sf_long)r;
+                while (i < nsrow) {
+                    const sf_long o = SuperMap[rows[i]];
+                    sf_long e = i;
+                    while (e < nsrow && SuperMap[rows[e]] == o) ++e;
+                    const double dn = (double)(e - i), dm = (double)(nsrow - e);
+                    f += dn * (dn + 1) * k + 2.0 * dm * dn * k;
+                    i = e;
+                }
+            }
+            if (lu) f *= 2.0;
+            if (owner[s] >= 0) { before[owner[s]] += f / 42e9; continue; }
+            const double rep = std::min(f, (lu ? 2.0 : 1.0) * 1472.0 * (r * k - 0.5 * k * k));
+            const double chain_ms = std::ceil(k / 64.0) * 0.045;
+            const int g = __builtin_popcount(mask[s]);
+            if (mask[s] == all) { root_ms += (f - rep) / 58e9; continue; }
+            for (int q = 0; q < nranks; ++q)
+                if ((mask[s] >> q) & 1u) before[q] += chain_ms + (rep + (f - rep) / std::max(g, 1)) / 48e9;
+        }
+        if (root_ms > 0.0) {
+            const double smin = 0.2 / nranks, smax = 3.0 / nranks;
+            double lo = *std::min_element(before.begin(), before.end()), hi = *std::max_element(before.begin(), before.end()) + root_ms;
+            std::vector<double> sh(nranks, 1.0 / nranks);
+            for (int it = 0; it < 60; ++it) {            // bisection on the common finishing time
+                const double T = 0.5 * (lo + hi);
+                double sum = 0.0;
+                for (int q = 0; q < nranks; ++q) sum += std::min(smax, std::max(smin, (T - before[q]) / root_ms));
+                if (sum > 1.0) hi = T; else lo = T;
+            }
+            double sum = 0.0;
+            for (int q = 0; q < nranks; ++q) { sh[q] = std::min(smax, std::max(smin, (0.5 * (lo + hi) - before[q]) / root_ms)); sum += sh[q]; }
+            cum.assign(nranks + 1, 0.0);
+            for (int q = 0; q < nranks; ++q) cum[q + 1] = cum[q] + sh[q] / sum;
+            cum[nranks] = 1.0;
+        }
+    }
+    return plan_create(out, device, lu, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, phase.data(), 2, rank, nranks, mask.data(),
+                       cum.empty() ? nullptr : cum.data());
 }
 
 int sf_chol_plan_create_mapped(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
@@ -1050,7 +1115,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, pc.pivinv, st); break;
             case 6: {       // k_update_small; a split launch (distributed top): this rank's share of the tiles (the update is a sum)
                 int64_t lo = 0, hi = L.count;
-                if (L.split) { lo = (int64_t)L.count * L.share_idx / L.share_cnt; hi = (int64_t)L.count * (L.share_idx + 1) / L.share_cnt; }
+                if (L.split) { lo = (int64_t)((double)L.count * L.share_lo); hi = L.share_hi >= 1.0 ? L.count : (int64_t)((double)L.count * L.share_hi); }
                 sf::launch_update_small(p->d_probs, p->d_stasks + L.first + lo, (int)(hi - lo), p->d_Lsx, p->d_relmap, st);
                 break;
             }
@@ -1063,8 +1128,9 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             case 4: {
                 uint32_t u0 = 0, u1 = L.units;
                 if (L.split) {
-                    u0 = (uint32_t)((uint64_t)L.units * (uint64_t)L.share_idx / (uint64_t)L.share_cnt);
-                    u1 = (uint32_t)((uint64_t)L.units * (uint64_t)(L.share_idx + 1) / (uint64_t)L.share_cnt);
+                    // the boundaries are the same doubles on the two ranks they separate: the windows tile [0, units) exactly
+                    u0 = (uint32_t)((double)L.units * L.share_lo);
+                    u1 = L.share_hi >= 1.0 ? L.units : (uint32_t)((double)L.units * L.share_hi);
                 }
                 sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, u0, u1,
                                 L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, p->gemm_dynamic ? p->d_info + 1 + L.ticket : nullptr, st);

@@ -28,8 +28,9 @@ struct Launch {
     int64_t prefix_first = 0;   // GEMM launches: first entry of this launch's K-step prefix (count + 1 entries)
     uint32_t units = 0;         // GEMM launches: total number of (tile, K step) units
     double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
-    bool split = false;         // distributed top: this rank executes share share_idx of share_cnt of this launch's units
+    bool split = false;         // distributed top: this rank executes the units [share_lo, share_hi) x units of this launch
     int share_idx = 0, share_cnt = 1;
+    double share_lo = 0.0, share_hi = 1.0;      // = share_idx / share_cnt, (share_idx + 1) / share_cnt unless the set's shares are weighted
     int ticket = 0;             // k_step launches: index of the launch's task-claim counter (d_info[1 + ticket])
 };
 
