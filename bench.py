@@ -178,7 +178,12 @@ def main():
     backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
     if "SF_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SF_BENCH_DEVICE"])
-    if world > 1:
+    # SF_FORCE_DISTRIBUTED=1 (rehearsal, never set by the driver): run the N > 1 code path -- nccl group, C-side RCCL communicator,
+    # mapped plan, sf_chol_plan_factorize_distributed -- with ONE rank on the single GPU of a test box
+    forced = os.environ.get("SF_FORCE_DISTRIBUTED") == "1" and world == 1
+    if forced:
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("MASTER_PORT", "29571")
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         import datetime
@@ -197,7 +202,7 @@ def main():
 
     lu = args.method == "lu"
     N = args.grid or (79 if lu else (1000 if args.workload == "stencil2d" else 128))
-    shard_one = world > 1 and args.mp.startswith("subtree")
+    shard_one = (world > 1 or forced) and args.mp.startswith("subtree")
     if lu and shard_one and args.mp != "subtree":
         raise SystemExit("sharded LU supports --mp subtree (distributed top) only")
     if shard_one and args.scale == "weak" and (lu or args.workload == "lap3d"):
@@ -438,7 +443,7 @@ def main():
         sharded.close()
     else:
         plan.close()
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

@@ -38,7 +38,11 @@ class _DevArray:
 
 class HipEngine:
     def __init__(self, sym, phase, load_top, device, rank=0, world=1, distributed=False, group=None, owner=None):
-        self.distributed = bool(distributed and world > 1)
+        import os
+        # SF_FORCE_DISTRIBUTED=1 (tests): take the distributed path even with one rank, so that the glue below -- unique id over
+        # torch.distributed, the C-side communicator, the mapped plan, sf_chol_plan_factorize_distributed -- runs on a one-GPU box
+        forced = os.environ.get("SF_FORCE_DISTRIBUTED") == "1"
+        self.distributed = bool(distributed and (world > 1 or forced))
         self.lu = bool(getattr(sym, "lu", False))
         if self.lu and world > 1 and not self.distributed:
             raise ValueError("sharded LU needs mode='distributed'")
@@ -76,7 +80,7 @@ class HipEngine:
                 if int(flag.item()) == 0 and self.comm is not None:
                     self.comm.close()
                     self.comm = None
-        if self.lu and world == 1:
+        if self.lu and world == 1 and self.comm is None:
             self.plan = LUPlan(sym, device=device)
         elif self.comm is not None:
             # proportionally mapped plan (a top supernode lives on the ranks below it), groups and their collectives handled by
@@ -152,7 +156,8 @@ class ShardedFactorization:
         if mode not in ("distributed", "replicated"):
             raise ValueError("mode must be 'distributed' or 'replicated'")
         self.sym, self.rank, self.world, self.group = sym, rank, world, group
-        self.mode = mode if world > 1 else "replicated"
+        import os
+        self.mode = mode if (world > 1 or os.environ.get("SF_FORCE_DISTRIBUTED") == "1") else "replicated"
         self.top_weight = (1.0 / world + TOP_CHAIN_SHARE) if self.mode == "distributed" else 1.0
         self.owner, self.top_fraction, self.max_load_fraction = subtree_partition(sym, world, self.top_weight)
         phase = phases_for_rank(self.owner, rank)
@@ -180,11 +185,12 @@ class ShardedFactorization:
     def factorize(self):
         import torch.distributed as dist
         eng = self.engine
-        eng.factorize_phase(0)
         if self.mode == "distributed" and getattr(eng, "comm", None) is not None:
-            eng.factorize_distributed()         # C driver + RCCL; asynchronous, finish() waits
+            # C driver + RCCL: sf_chol_plan_factorize_distributed runs phase 0 AND the segments; asynchronous, finish() waits
+            eng.factorize_distributed()
             eng.finish()
             return
+        eng.factorize_phase(0)
         if self.mode == "distributed":
             for k in range(eng.num_segments()):
                 for t in eng.segment_tensors(k):

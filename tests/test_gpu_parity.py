@@ -325,6 +325,23 @@ def test_rccl_world1_collectives_on_plan_memory():
     assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, p.stdout[-3000:]
 
 
+def test_rccl_c_path_glue_one_rank():
+    """the multi-GPU product path end to end on a one-rank nccl group (tests/_rccl_c_glue_worker.py): unique id over
+    torch.distributed, communicator made by the C library, mapped plan, sf_chol_plan_factorize_distributed, Cholesky and LU"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SF_FORCE_DISTRIBUTED="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "_rccl_c_glue_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "RCCL_C_GLUE_OK" in p.stdout, p.stdout[-3000:]
+
+
 @pytest.mark.parametrize("case", small_cases(), ids=lambda c: c[0])
 def test_device_solve_matches_oracle(oracle, case):
     """sf_chol_plan_solve (level-scheduled, factor resident) vs the reference's host loops (oracle restatement)"""
