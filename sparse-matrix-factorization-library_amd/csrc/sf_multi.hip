@@ -217,6 +217,7 @@ int sf_comm_create_all(sf_comm** comms, int nranks, const int* devices) {
 int sf_comm_prepare_groups(sf_comm* c, const uint32_t* masks, int nmasks) {
     if (!c || (nmasks > 0 && !masks)) return SF_ERR_ARG;
     const uint32_t all = c->nranks >= 32 ? 0xffffffffu : ((1u << c->nranks) - 1u);
+    HIP_TRY(hipSetDevice(c->device));       // a handler thread starts with device 0 current: RCCL calls are made with the communicator's device
     for (int k = 0; k < nmasks; ++k) {
         const uint32_t m = masks[k] & all;
         if (m == all || m == 0) continue;                       // the world itself / nobody
@@ -336,6 +337,7 @@ int sf_comm_allreduce_sum(sf_comm* c, void* device_buf, sf_long count, void* str
     if (count < 0 && c->kind != 1) return SF_ERR_ARG;
     if (c->kind == 1) return c->nranks == 1 ? SF_OK : local_allreduce(c, (double*)device_buf, count, (hipStream_t)stream);
     if (count == 0) return SF_OK;
+    HIP_TRY(hipSetDevice(c->device));
     NCCL_TRY(rccl().AllReduce(device_buf, device_buf, (size_t)count, ncclDouble, ncclSum, c->nccl, (hipStream_t)stream));
     return SF_OK;
 }
