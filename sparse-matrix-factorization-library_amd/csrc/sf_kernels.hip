@@ -1441,7 +1441,9 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
+#ifndef SF_EXP_NO_RELEASE_FENCE     // timing ablation only (tools/experiments/step_fence.sh): what the device-scope release costs
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flags + t.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1457,7 +1459,9 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             __builtin_amdgcn_s_sleep(16);
             if (++spins > ST_SPIN_LIMIT) { atomicOr(info, 2); break; }
         }
+#ifndef SF_EXP_NO_ACQUIRE_FENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
