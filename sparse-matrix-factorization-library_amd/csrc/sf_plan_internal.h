@@ -82,6 +82,10 @@ struct DlPiece {
     int64_t dev_off, host_off, count;   // doubles; LU: dev_off unused (the piece is packed from the (L, U^T) panels)
     size_t ready;
     int ev;
+    // Cholesky block columns right of the first one: the rows above the block's first column are structurally zero (never written on
+    // the device either), so only rows [skip, ld) of each of the `ncols` columns cross PCIe (count = ncols * (ld - skip), a 2-D
+    // copy) and the host side zero-fills the prefixes.  ld == 0: a plain contiguous piece.
+    int64_t skip = 0, ld = 0, ncols = 0;
 };
 
 struct sf_comm;      // one rank's end of a multi-GPU group (sf_multi.hip)
