@@ -112,8 +112,13 @@ def secondary_case(sf, np, kind, steps=3):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_config3.json")))
         if files:
             with open(files[-1]) as f:
-                traffic = json.load(f).get("_total", {}).get("hbm_bytes_per_factorization")
-            src = "committed rocprofv3 --pmc passes: " + os.path.basename(files[-1])
+                pm = json.load(f)
+            # the factorization's kernels only: the profiled run also solves (k_solve_*) and validates (k_resid_*)
+            fk = [v for k, v in pm.items() if isinstance(v, dict) and "hbm_bytes_total" in v
+                  and not (k.startswith("k_solve") or k.startswith("k_resid"))]
+            nf = max(int(pm.get("_total", {}).get("factorizations_in_the_run", 1)), 1)
+            traffic = sum(v["hbm_bytes_total"] for v in fk) / nf if fk else pm.get("_total", {}).get("hbm_bytes_per_factorization")
+            src = "committed rocprofv3 --pmc passes (factorization kernels; solve and residual kernels excluded): " + os.path.basename(files[-1])
         out["roofline"] = {"bound": "hbm", "kernel": "whole factorization (level-scheduled: latency-bound, see DESIGN 5)",
                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                            "algorithmic_bytes": alg, "scatter_elems": E, "traffic": traffic, "traffic_source": src}
