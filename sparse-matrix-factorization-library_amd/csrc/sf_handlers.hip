@@ -95,8 +95,10 @@ struct Resident {
     std::shared_ptr<SolverSlot> slot;
     int device = 0;
 };
-std::mutex g_res_mu;
-std::unordered_map<const void*, Resident> g_resident;
+// (leaked on purpose: a process that exits with entries still registered -- no SparseFrame_free_gpu -- must not run plan destructors,
+// i.e. HIP calls, from a static destructor after the runtime has been torn down)
+std::mutex& g_res_mu = *new std::mutex();
+std::unordered_map<const void*, Resident>& g_resident = *new std::unordered_map<const void*, Resident>();
 int64_t g_resident_solves = 0;      // solves served from a resident factor (tests)
 void forget_plan(sf_chol_plan* plan) {
     std::lock_guard<std::mutex> g(g_res_mu);
