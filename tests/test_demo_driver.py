@@ -93,3 +93,23 @@ def test_demo_reports_a_bad_matrix_and_goes_on(tmp_path):
     assert r.returncode == 1
     assert "bad.mtx: SparseFrame_factorize failed with code 4" in r.stderr
     assert len(_residuals(r.stdout)) == 1 and "Matrix name:    good.mtx" in r.stdout
+
+
+C_SMOKE = os.path.join(PKG, "sf_c_abi_smoke")
+
+
+def test_c99_program_builds_and_fails_loudly_without_gpu():
+    """examples/c_abi_smoke.c: the headers compile as strict C99 with a plain C compiler and link against the library"""
+    assert os.path.exists(C_SMOKE)
+    if sf.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    r = _run(C_SMOKE, [])
+    assert r.returncode == 4 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c99_program_through_the_struct_entry_points():
+    r = _run(C_SMOKE, [])
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"C ABI residual ([0-9.eE+-]+)", r.stdout)
+    assert m and float(m.group(1)) <= 1e-14
