@@ -113,3 +113,16 @@ def test_c99_program_through_the_struct_entry_points():
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"C ABI residual ([0-9.eE+-]+)", r.stdout)
     assert m and float(m.group(1)) <= 1e-14
+
+
+PLAN_LOOP = os.path.join(PKG, "sf_plan_loop")
+
+
+@pytest.mark.gpu
+def test_c99_plan_loop_example():
+    """examples/plan_loop.c: the flat plan ABI from C -- one analysis, one plan, four factorizations of new values, device solve
+    and device validate each time"""
+    r = _run(PLAN_LOOP, [])
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = [float(x) for x in re.findall(r"residual ([0-9.eE+-]+)", r.stdout)]
+    assert len(res) == 4 and max(res) <= 1e-13
