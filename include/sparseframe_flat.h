@@ -213,6 +213,11 @@ int sf_comm_destroy(sf_comm *comm);
 /* test hook: split the communicator (all ranks, one colour), all-reduce on the child, destroy it */
 int sf_comm_selftest_split(sf_comm *comm, void *device_buf, sf_long count, void *hip_stream);
 int sf_chol_plan_factorize_distributed(sf_chol_plan *plan, sf_comm *comm, sf_float *host_out /* or NULL */, int sync);
+/* The solve with a factor that stays distributed (mapped plans after sf_chol_plan_factorize_distributed; Cholesky and LU): b_host =
+ * the whole right-hand side in the permuted numbering on every rank; every rank writes into x_host the entries it is responsible
+ * for (its subtrees' columns + the columns of the shared supernodes whose group it leads), the others are left alone.  One small
+ * sum per shared supernode in the forward sweep is all that travels. */
+int sf_chol_plan_solve_distributed(sf_chol_plan *plan, sf_comm *comm, const sf_float *b_host, sf_float *x_host);
 
 /* ---- device plan for supernodal no-pivot LU (replaces L:2668-3573 + LU/Source/cuda_kernel.cu:22-176).
  * Symbolic arrays from sf_symbolic_create_lu; Lsxp is the reference's (packed (2*nsrow-nscol) x nscol) offsets.

@@ -224,6 +224,14 @@ class _ShardedPlanMixin:
         out = _dp(host_out) if host_out is not None else None
         check(lib.sf_chol_plan_factorize_distributed(self._h, comm._h, out, 1 if sync else 0), "sf_chol_plan_factorize_distributed")
 
+    def solve_distributed(self, comm, b):
+        """the solve with the factor left distributed (sf_chol_plan_solve_distributed): returns x with this rank's entries filled
+        in (its subtrees' columns, the shared supernodes it leads) and zeros elsewhere -- the sum over the ranks is the solution"""
+        b = _f64(b)
+        x = np.zeros_like(b)
+        check(lib.sf_chol_plan_solve_distributed(self._h, comm._h, _dp(b), _dp(x)), "sf_chol_plan_solve_distributed")
+        return x
+
     def factorize_phase(self, which, sync=True):
         check(lib.sf_chol_plan_factorize_phase(self._h, which, 1 if sync else 0), "sf_chol_plan_factorize_phase")
 

@@ -578,9 +578,31 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // per (level, SV_B-column step): a forward launch [diagonal tasks, SV_ROWS-row tiles] and a backward launch [tiles, diagonal tasks]
     std::vector<sf::SolveTask> solve;
     int32_t n_solve_sync = 0;
-    if (!p->partial) {
+    // A mapped plan (create_mapped: one rank's subtrees + the top supernodes above them) gets a schedule too, over the panels it
+    // stores -- the distributed solve (sf_chol_plan_solve_distributed, sf_multi.hip):
+    //   forward   x[columns of a shared supernode] is summed over its group before the supernode's first step (the right-hand side
+    //             is loaded by the group's first rank only, every rank adds the updates of its own descendants); the diagonal
+    //             solves and the tiles inside the supernode's own columns are replicated in the group, the tiles that update
+    //             ANCESTORS' rows are dealt out over the group (their sums meet again at the ancestor's reduce point);
+    //   backward  no communication: every rank of a group solves the group's supernodes in full (it holds the panels and, by
+    //             then, the solution of all their ancestors).
+    const bool solve_mapped = p->partial && top_mask != nullptr && load_top == 2;
+    if (!p->partial || solve_mapped) {
         std::vector<std::vector<sf_long>> by_level(nlevels);
-        for (sf_long s = 0; s < nsuper; ++s) by_level[level[s]].push_back(s);
+        for (sf_long s = 0; s < nsuper; ++s)
+            if (XP[s] >= 0) by_level[level[s]].push_back(s);
+        auto shared_sn = [&](sf_long s) { return solve_mapped && p->phase[s] == 1 && __builtin_popcount(gmask[s]) > 1; };
+        if (solve_mapped) {
+            for (sf_long s = 0; s < nsuper; ++s) {
+                if (XP[s] < 0) continue;
+                const bool first = p->phase[s] == 0 || group_idx(gmask[s]) == 0;
+                if (first) {
+                    if (!p->solve_own.empty() && p->solve_own.back().second == Super[s]) p->solve_own.back().second = Super[s + 1];
+                    else p->solve_own.push_back({Super[s], Super[s + 1]});
+                }
+            }
+            p->solve_load = p->solve_own;
+        }
         const int tile = sf::SV_ROWS;
         // default: fused (35.3 ms at 128^3); SF_SOLVE_BWD_FUSED=0: two launches per backward step (38.2 ms)
         const bool bwd_fused = !(getenv("SF_SOLVE_BWD_FUSED") && atoi(getenv("SF_SOLVE_BWD_FUSED")) == 0);
@@ -591,8 +613,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             // the narrow panels of the level (nscol <= 64; the swarm levels consist of nothing else) go to the
             // one-wave-per-supernode kernels as a step of their own, the wide ones through the general 256-column steps
             std::vector<sf_long> narrow, wide;
-            for (sf_long s : by_level[l]) ((Super[s + 1] - Super[s] <= sf::NB) ? narrow : wide).push_back(s);
+            for (sf_long s : by_level[l]) ((Super[s + 1] - Super[s] <= sf::NB && !shared_sn(s)) ? narrow : wide).push_back(s);
             if (narrow.size() < 64) { wide = by_level[l]; narrow.clear(); }     // not worth a launch of their own
+            // sums that precede this level's first step: the columns of its shared supernodes, each inside its group
+            const int red_first = (int)p->solve_reduces.size();
+            for (sf_long s : wide)
+                if (shared_sn(s)) p->solve_reduces.push_back(sf_chol_plan::SolveReduce{Super[s], Super[s + 1] - Super[s], gmask[s]});
+            int red_count = (int)p->solve_reduces.size() - red_first;
             if (!narrow.empty()) {
                 sf_chol_plan::SolveStep st{};
                 st.small = 1;
@@ -601,28 +628,45 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
                     solve.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, 0, nscol, 0, 0, (int32_t)Super[s], 0, 0});
                 }
-                st.count = st.ndiag = (int)narrow.size();
+                st.count = st.ndiag = st.fwd_count = (int)narrow.size();
+                st.red_first = red_first; st.red_count = 0;
                 p->solve_steps.push_back(st);
             }
             maxcol = 0;
             for (sf_long s : wide) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
             for (int diag = 0; diag < maxcol; diag += sf::SV_B) {
                 sf_chol_plan::SolveStep st{};
-                std::vector<sf::SolveTask> dg, rows;
+                std::vector<sf::SolveTask> dg, rows, rows_fwd;
                 for (sf_long s : wide) {
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
                     if (diag >= nscol) continue;
                     const int b = std::min(sf::SV_B, nscol - diag);
-                    const int ntiles = (nsrow - diag - b + tile - 1) / tile;
+                    const bool sh = shared_sn(s);
+                    // a shared supernode's tiles are cut at the end of its own columns: the ones inside are replicated in the
+                    // group, the ones below (ancestors' rows) are dealt out in the forward sweep
+                    int ntiles = 0;
+                    const int cut = sh ? std::max(nscol, diag + b) : nsrow;
+                    const int g = sh ? __builtin_popcount(gmask[s]) : 1, gi = sh ? group_idx(gmask[s]) : 0;
+                    int below = 0;
+                    for (int r0 = diag + b, r1 = cut; r0 < nsrow; r0 = r1, r1 = nsrow) {
+                        for (int r = r0; r < r1; r += tile) {
+                            const sf::SolveTask t{XP[s], Lsip[s], nsrow, diag, b, r, std::min(tile, r1 - r), (int32_t)Super[s], n_solve_sync, 0};
+                            rows.push_back(t);
+                            ++ntiles;
+                            if (!sh || r < nscol || (below++ % g) == gi) rows_fwd.push_back(t);
+                        }
+                        if (r1 >= nsrow) break;
+                    }
                     // sync words: [flag] forward "solved" flag, [flag + 1] backward tile counter
                     dg.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, b, 0, 0, (int32_t)Super[s], n_solve_sync, ntiles});
-                    for (int r = diag + b; r < nsrow; r += tile)
-                        rows.push_back(sf::SolveTask{XP[s], Lsip[s], nsrow, diag, b, r, std::min(tile, nsrow - r), (int32_t)Super[s], n_solve_sync, 0});
                     n_solve_sync += 2;
                 }
                 st.fwd_first = (int64_t)solve.size();
                 solve.insert(solve.end(), dg.begin(), dg.end());
-                solve.insert(solve.end(), rows.begin(), rows.end());
+                solve.insert(solve.end(), rows_fwd.begin(), rows_fwd.end());
+                st.fwd_count = (int)(dg.size() + rows_fwd.size());
+                st.red_first = red_first; st.red_count = red_count;
+                red_count = 0;                      // the sums belong to the level's first step
                 st.bwd_first = (int64_t)solve.size();
                 for (sf::SolveTask t : rows) { t.flag += 1; solve.push_back(t); }
                 // backward: one launch, the diagonal task waits for a tile counter (SF_SOLVE_BWD_FUSED=0: the row tiles and
@@ -1741,7 +1785,7 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
                                        (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, st);
             continue;
         }
-        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.count, s.big, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
+        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.fwd_count, s.big, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
                              (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, sync, tickets + 3 * k,
                              p->d_solve_sync, st);
     }

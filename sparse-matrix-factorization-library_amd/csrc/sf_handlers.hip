@@ -93,6 +93,7 @@ struct Resident {
     std::vector<sf_chol_plan*> parts;
     std::vector<int> part_epochs;
     std::shared_ptr<SolverSlot> slot;
+    std::vector<sf_comm*> comms;        // the ranks' communicators (owned by the handler list), for the distributed solve
     int device = 0;
 };
 // (leaked on purpose: a process that exits with entries still registered -- no SparseFrame_free_gpu -- must not run plan destructors,
@@ -231,6 +232,7 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
         R.parts = entry->plans;
         for (sf_chol_plan* q : entry->plans) R.part_epochs.push_back(q->epoch);
         R.slot = entry->slot;
+        R.comms = M.comms;
         R.device = list[0].gpuIndex_physical;
         std::lock_guard<std::mutex> g(g_res_mu);
         g_resident[(const void*)Lsx_out] = std::move(R);
@@ -420,6 +422,45 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
         for (size_t r = 0; r < R.parts.size(); ++r)
             if (R.parts[r]->epoch != R.part_epochs[r]) { g_resident.erase(it); return why("a rank's plan holds a later factorization"); }
         SolverSlot& S = *R.slot;
+        // The factor stays where it is and the ranks solve together (sf_chol_plan_solve_distributed), one host thread per rank as in
+        // the factorization.  SF_SOLVE=gather: gather the panels into a whole plan on the first handler's device instead (below).
+        bool distributed = true;
+        if (const char* e = getenv("SF_SOLVE")) distributed = strcmp(e, "gather") != 0;
+        if (distributed && R.comms.size() == R.parts.size()) {
+            // the host copy must still be what the devices hold: the first window of the first panel each of three ranks stores
+            // (Cholesky: a stored panel is a contiguous run in both layouts; LU panels are packed on the way out, not compared here)
+            const size_t N = R.parts.size();
+            if (!R.parts[0]->lu && Lsxp) {
+                for (size_t r : {(size_t)0, N / 2, N - 1}) {
+                    sf_chol_plan* P = R.parts[r];
+                    sf_long s0 = 0;
+                    while (s0 < P->nsuper && P->h_XP[s0] < 0) ++s0;
+                    if (s0 >= P->nsuper) continue;
+                    const sf_long w = std::min<sf_long>(512, Lsxp[s0 + 1] - Lsxp[s0]);
+                    std::vector<double> dev((size_t)w);
+                    if (hipSetDevice(P->device) != hipSuccess ||
+                        hipMemcpy(dev.data(), P->d_Lsx + P->h_XP[s0], (size_t)w * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                        return why("reading a rank's panel failed");
+                    double amax = 0.0, dmax = 0.0;
+                    for (sf_long i = 0; i < w; ++i) {
+                        const double h = Lsx_host[Lsxp[s0] + i], d = dev[(size_t)i];
+                        if (!(h == h) || !(d == d)) continue;
+                        amax = std::max(amax, std::fabs(h));
+                        dmax = std::max(dmax, std::fabs(h - d));
+                    }
+                    if (!(dmax <= 1e-10 * amax)) { g_resident.erase(it); return why("the host copy differs from a rank's panel (sampled)"); }
+                }
+            }
+            std::vector<int> rcs(N, SF_OK);
+            std::vector<std::thread> th;
+            for (size_t r = 0; r < N; ++r)
+                th.emplace_back([&, r] { rcs[r] = sf_chol_plan_solve_distributed(R.parts[r], R.comms[r], b, x); });
+            for (std::thread& t : th) t.join();
+            for (size_t r = 0; r < N; ++r)
+                if (rcs[r]) return why("the distributed solve failed");
+            ++g_resident_solves;
+            return SF_OK;
+        }
         if (!S.plan) {
             if (!Super || !SuperMap || !Lsip || !Lsi || !Lsxp || !Lp || !Li || nsuper <= 0) return why("distributed factor and no symbolic arrays");
             size_t free_b = 0, total_b = 0;

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <vector>
 
+#include "sf_kernels.h"
 #include "sf_plan_internal.h"
 
 namespace {
@@ -346,6 +347,69 @@ int sf_comm_allreduce_sum(sf_comm* c, void* device_buf, sf_long count, void* str
 // sf_lu_plan_create_distributed with the same rank / nranks as `comm`): own subtrees, then for every segment the
 // parent-front merge (one all-reduce of the packed block columns) and the segment's launches.  host_out != NULL: the
 // pieces of the factor this rank is responsible for are copied into it while the factorization runs.
+// The solve with a factor that stays distributed over the ranks' mapped plans (create_mapped), after
+// sf_chol_plan_factorize_distributed: see the schedule in sf_chol_plan.hip ("distributed solve").  b_host: the whole right-hand
+// side (permuted numbering) on every rank; x_host: every rank writes the entries it is responsible for (its subtrees' columns, and
+// the columns of the shared supernodes whose group it leads) and leaves the others alone -- ranks that are threads of one process
+// may share one x_host, separate processes merge theirs (the entries of a column range come from exactly one rank).
+// The only communication is one small sum per shared supernode in the forward sweep (its columns of x, inside its group).
+int sf_chol_plan_solve_distributed(sf_chol_plan* p, sf_comm* comm, const sf_float* b_host, sf_float* x_host) {
+    if (!p || !comm || !b_host || !x_host || comm->nranks != p->nranks || comm->rank != p->rank) return SF_ERR_ARG;
+    if (p->nranks == 1 && !p->partial) return sf_chol_plan_solve(p, b_host, x_host);
+    if (p->nsuper > 0 && (!p->d_solve || (p->solve_own.empty() && p->solve_steps.empty()))) return SF_ERR_ARG;
+    int rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size());
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = p->stream;
+    const int64_t n = p->n;
+    if (n <= 0) return SF_OK;
+    // right-hand side: the columns this rank loads (the others start from zero: they only collect this rank's updates)
+    std::vector<double> xb((size_t)n, 0.0);
+    for (const auto& r : p->solve_load)
+        memcpy(xb.data() + r.first, b_host + r.first, (size_t)(r.second - r.first) * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(p->d_x, xb.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    const double* fwd_base = p->d_Lsx;
+    const double* bwd_base = p->lu ? p->d_Lsx + p->xC : p->d_Lsx;
+    const size_t nst = p->solve_steps.size();
+    int* sync = p->d_solve_sync + 1;
+    int* tickets = sync + p->n_solve_sync;
+    if (p->d_solve_sync) HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + 3 * nst) * sizeof(int), st));
+    const int32_t* piv = (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr;
+    for (size_t k = 0; k < nst && !rc; ++k) {
+        const auto& s = p->solve_steps[k];
+        for (int q = 0; q < s.red_count && !rc; ++q) {
+            const auto& R = p->solve_reduces[(size_t)s.red_first + q];
+            sf_comm* gc = group_comm(comm, R.mask);
+            rc = gc ? sf_comm_allreduce_sum(gc, (void*)(p->d_x + R.off), R.cnt, (void*)st) : SF_ERR_ARG;
+        }
+        if (rc) break;
+        if (s.small) sf::launch_solve_small_fwd(p->d_solve + s.fwd_first, s.ndiag, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0, piv, st);
+        else sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.fwd_count, s.big, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0, piv, sync,
+                                  tickets + 3 * k, p->d_solve_sync, st);
+    }
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    for (size_t k = nst; k-- > 0;) {
+        const auto& s = p->solve_steps[k];
+        if (s.small) sf::launch_solve_small_bwd(p->d_solve + s.bwd_first, s.ndiag, bwd_base, p->d_Lsi, p->d_x, st);
+        else if (p->solve_bwd_fused)
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
+        else {
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.nrows_tasks, 0, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first + s.nrows_tasks, s.count - s.nrows_tasks, s.big, bwd_base, p->d_Lsi, p->d_x, sync,
+                                 tickets + 3 * k + 2, p->d_solve_sync, st);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(xb.data(), p->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    int sinfo = 0;
+    if (p->d_solve_sync) HIP_TRY(hipMemcpyAsync(&sinfo, p->d_solve_sync, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sinfo) return SF_ERR_HIP;
+    for (const auto& r : p->solve_own)
+        memcpy(x_host + r.first, xb.data() + r.first, (size_t)(r.second - r.first) * sizeof(double));
+    return SF_OK;
+}
+
 int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float* host_out, int sync) {
     if (!p || !comm || comm->nranks != p->nranks || comm->rank != p->rank) return SF_ERR_ARG;
     if (p->nranks == 1) {

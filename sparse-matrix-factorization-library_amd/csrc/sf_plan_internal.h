@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "sf_kernels.h"
@@ -149,7 +150,14 @@ struct sf_chol_plan {
     sf::SolveTask* d_solve = nullptr;
     double* d_x = nullptr;
     double* d_resid = nullptr;  // sf_chol_plan_validate: r | column sums | b | 4 norms
-    struct SolveStep { int64_t fwd_first, bwd_first; int count; int big; int nrows_tasks; int small; int ndiag; };   // both launches of a step have `count` tasks; big: a panel of the step is wider than 64 columns
+    // the forward launch of a step has fwd_count tasks, the backward one `count` (equal unless the plan is one rank's part of a
+    // distributed factor: the forward tiles that update ancestors' rows are dealt out over the group, the backward ones are not);
+    // big: a panel of the step is wider than 64 columns; red_first / red_count: sums over a group that precede the forward launch
+    struct SolveStep { int64_t fwd_first, bwd_first; int count; int big; int nrows_tasks; int small; int ndiag; int fwd_count; int red_first, red_count; };
+    struct SolveReduce { int64_t off, cnt; uint32_t mask; };        // x[off .. off + cnt) summed over the ranks of `mask`
+    std::vector<SolveReduce> solve_reduces;
+    std::vector<std::pair<int64_t, int64_t>> solve_own;           // column ranges whose solution this rank reports (distributed solve)
+    std::vector<std::pair<int64_t, int64_t>> solve_load;          // column ranges whose right-hand side this rank loads
     int* d_solve_sync = nullptr;
     bool solve_bwd_fused = false;
     int n_solve_sync = 0;

@@ -207,6 +207,23 @@ class ShardedFactorization:
                     torch.cuda.synchronize(top.device)
         eng.factorize_phase(1)
 
+    def solve(self, b):
+        """x = A^{-1} b (permuted numbering) with the factor left where the factorization put it: the C driver's distributed solve
+        (one small sum per shared supernode inside the library), then the ranks' parts of x are merged with one all-reduce"""
+        import torch
+        import torch.distributed as dist
+        eng = self.engine
+        if getattr(eng, "comm", None) is None:
+            if self.world > 1:
+                raise RuntimeError("the distributed solve needs the C-side communicator (nccl backend)")
+            return eng.plan.solve(b)
+        x = eng.plan.solve_distributed(eng.comm, b)
+        if self.world > 1:
+            t = torch.from_numpy(x).cuda(eng.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            x = t.cpu().numpy()
+        return x
+
     def gather_factor(self):
         """full factor in the reference layout on every rank (all-reduce of the disjoint subtree panels; the
         top panels, identical on every rank, are taken from this rank).  Test / validation helper, not part of the

@@ -47,6 +47,20 @@ def main():
             S.factorize()
         got = S.gather_factor()
         assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref)), method
+        b = 1.0 + np.arange(n) / n
+        x = S.solve(b)                              # sf_chol_plan_solve_distributed through the same glue
+        lc = np.repeat(np.arange(n), np.diff(sym.Lp))
+        import scipy.sparse as sp
+        A = sp.coo_matrix((sym.Lx, (sym.Li, lc)), shape=(n, n)).tocsr()
+        if method == "lu":
+            ur = np.repeat(np.arange(n), np.diff(sym.Up))
+            off = sym.Ui != ur
+            A = A + sp.coo_matrix((sym.Ux[off], (ur[off], sym.Ui[off])), shape=(n, n)).tocsr()
+        else:
+            off = sym.Li != lc
+            A = A + sp.coo_matrix((sym.Lx[off], (lc[off], sym.Li[off])), shape=(n, n)).tocsr()
+        r = A @ x - b
+        assert np.abs(r).max() / (abs(A).sum(axis=0).max() * np.abs(x).max() + np.abs(b).max()) <= 1e-13, method
         S.close()
     torch.cuda.synchronize()
     dist.barrier()

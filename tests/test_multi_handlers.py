@@ -89,9 +89,11 @@ def test_emulated_handlers_large_by_residual(monkeypatch, nh, N):
 
 @pytest.mark.parametrize("method", ["cholesky", "lu"])
 def test_struct_solve_after_multi_handler_factorization(monkeypatch, method):
-    """after a factorization by several handlers the factor is spread over their plans; SparseFrame_solve_supernodal gathers it
-    (device to device) into a whole plan on the first handler's device and solves there, again after a refactorization; same
-    solution as the reference's host solve over Lsx"""
+    """after a factorization by several handlers the factor is spread over their plans; with SF_SOLVE=gather
+    SparseFrame_solve_supernodal gathers it (device to device) into a whole plan on the first handler's device and solves there,
+    again after a refactorization; same solution as the reference's host solve over Lsx.  (Default: the distributed solve, next
+    test.)"""
+    monkeypatch.setenv("SF_SOLVE", "gather")
     if sf.device_count() != 1:
         pytest.skip("emulated handlers are for one-GPU boxes")
     from importlib import import_module
@@ -122,9 +124,46 @@ def test_struct_solve_after_multi_handler_factorization(monkeypatch, method):
         assert mi.validate() <= TOL_RESIDUAL
         assert lib.sf_handlers_resident_solves() == k + 1
         x_host = mi.array("Xx", n).copy()
-        monkeypatch.delenv("SF_SOLVE")
+        monkeypatch.setenv("SF_SOLVE", "gather")
         assert np.max(np.abs(x_dev - x_host)) <= 1e-12 * np.max(np.abs(x_host))
         mi.cleanup()
+    common.close()
+
+
+@pytest.mark.parametrize("method,nh,N", [("cholesky", 2, 24), ("cholesky", 3, 34), ("cholesky", 8, 40), ("lu", 2, 14), ("lu", 4, 24)])
+def test_distributed_solve_with_the_factor_left_on_the_ranks(monkeypatch, method, nh, N):
+    """after a multi-handler factorization the ranks solve together with the panels they hold -- one small
+    sum per shared supernode in the forward sweep, none in the backward one -- instead of gathering the factor on one device;
+    same solution as the reference's host solve over Lsx.  34^3 / 40^3: shared supernodes of several 256-column steps, groups of
+    2, 4 and 8"""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    from importlib import import_module
+    lib = import_module("sparse-matrix-factorization-library_amd._lib").lib
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", str(nh))
+    if method == "lu":
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=11)
+        mi = sf.LUMatrixInfo()
+        kw = dict(symmetric=False)
+    else:
+        n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+        mi = sf.MatrixInfo()
+        kw = {}
+    common = sf.CommonInfo(dev_slot_size=8 << 30)
+    assert common.c.numGPU == nh
+    mi.set_csc(n, Cp, Ci, Cx, **kw)
+    mi.set_perm(nd_perm_py(N, N, N))
+    mi.analyze(common)
+    mi.factorize(common)
+    k = lib.sf_handlers_resident_solves()                  # default for a multi-handler factor: the distributed solve
+    assert mi.validate() <= TOL_RESIDUAL
+    assert lib.sf_handlers_resident_solves() == k + 1
+    x_dist = mi.array("Xx", n).copy()
+    monkeypatch.setenv("SF_SOLVE", "host")
+    assert mi.validate() <= TOL_RESIDUAL
+    x_host = mi.array("Xx", n).copy()
+    assert np.max(np.abs(x_dist - x_host)) <= 1e-12 * np.max(np.abs(x_host))
+    mi.cleanup()
     common.close()
 
 
