@@ -348,6 +348,34 @@ def main():
                            "small_update_ms": round(plan.stat("last_small_update_ms"), 3),
                            "launches": int(plan.stat("launches")), "levels": int(plan.stat("levels"))}
 
+    if sharded is not None and sharded.mode == "distributed" and getattr(sharded.engine, "comm", None) is not None:
+        # correctness of the multi-GPU run, outside the timed region: the distributed solve with the factor left on the ranks
+        # (every rank takes part), then the reference's validate() residual on rank 0 (numpy over the analysed matrix)
+        try:
+            bvec = 1 + np.arange(n) / n
+            t_s = time.perf_counter()
+            xs = sharded.solve(bvec)
+            solve_ms = (time.perf_counter() - t_s) * 1e3
+            if rank == 0:
+                if lu:
+                    lc = np.repeat(np.arange(n), np.diff(sym.Lp))
+                    rr = -bvec.copy()
+                    np.add.at(rr, sym.Li, sym.Lx * xs[lc])
+                    ur = np.repeat(np.arange(n), np.diff(sym.Up))
+                    off = sym.Ui != ur
+                    np.add.at(rr, ur[off], sym.Ux[off] * xs[sym.Ui[off]])
+                    colsum = np.zeros(n)
+                    np.add.at(colsum, lc, np.abs(sym.Lx))
+                    np.add.at(colsum, sym.Ui[off], np.abs(sym.Ux[off]))
+                    res = float(np.abs(rr).max() / (colsum.max() * np.abs(xs).max() + np.abs(bvec).max()))
+                else:
+                    res = sf.validate_solution(sym, xs)
+                out["config"]["residual_distributed_solve"] = res
+                out["config"]["distributed_solve_wall_ms"] = round(solve_ms, 3)
+        except Exception as e:      # noqa: BLE001 -- the throughput line must not be lost to a failing check
+            if rank == 0:
+                out["config"]["residual_distributed_solve"] = f"failed: {e}"
+
     if rank == 0 and sharded is None:
         # the reference's validate() with nothing leaving the device but the scalar: solve with the resident factor and
         # residual kernels over the plan's copy of A (sf_chol_plan_validate); the numpy form of the same residual is the
