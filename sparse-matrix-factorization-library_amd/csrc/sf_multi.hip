@@ -356,9 +356,10 @@ int sf_comm_allreduce_sum(sf_comm* c, void* device_buf, sf_long count, void* str
 int sf_chol_plan_solve_distributed(sf_chol_plan* p, sf_comm* comm, const sf_float* b_host, sf_float* x_host) {
     if (!p || !comm || !b_host || !x_host || comm->nranks != p->nranks || comm->rank != p->rank) return SF_ERR_ARG;
     if (p->nranks == 1 && !p->partial) return sf_chol_plan_solve(p, b_host, x_host);
-    if (p->nsuper > 0 && (!p->d_solve || (p->solve_own.empty() && p->solve_steps.empty()))) return SF_ERR_ARG;
-    int rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size());
+    int rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size());     // collective: before any early return
     if (rc) return rc;
+    if (p->solve_steps.empty()) return SF_OK;               // a rank that stores nothing (more ranks than subtrees) reports nothing
+    if (!p->d_solve || !p->d_x) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
     const int64_t n = p->n;
