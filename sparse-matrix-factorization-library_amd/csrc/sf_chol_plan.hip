@@ -285,6 +285,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // stay covered by the tests
     int64_t fuse_max = 32 * sf::GEMM_GRID;
     if (const char* env = getenv("SF_FUSE_MAX")) fuse_max = strtoll(env, nullptr, 10);
+    // LU: the look-ahead schedule adds the near part of a block's update on every rank separately (k_gemm's fp64 atomics: the order
+    // of the additions, hence the last bits, differ from rank to rank), and a threshold pivot decision taken on such a block could
+    // differ between the ranks of a group, whose copies of the panel must stay interchangeable.  Without it everything a chain
+    // reads is bit-identical inside the group (all-reduced sums; the step kernels add in a fixed order).  So LU keeps the in-line
+    // sums unless asked (SF_LOOKAHEAD=1, e.g. with pivoting off).
+    if (lu) p->lookahead = false;
     if (const char* env = getenv("SF_LOOKAHEAD")) p->lookahead = atoi(env) != 0;      // 0: the round-1 schedule (tests cover both)
     // The sweep: one set of independent supernodes at a time -- phase 0: a level of the owned subtrees; phase 1: the top
     // supernodes of one level that share one group of ranks (ascending mask: every rank meets the sets it shares with

@@ -168,9 +168,12 @@ def test_distributed_solve_with_the_factor_left_on_the_ranks(monkeypatch, method
 
 
 def test_lookahead_schedule_lu(oracle, monkeypatch):
+    """LU keeps the in-line sums by default (pivot decisions must not depend on a rank's own rounding, see plan_create);
+    SF_LOOKAHEAD=1 selects the look-ahead schedule for it -- same factor on this diagonally dominant matrix"""
     if sf.device_count() != 1:
         pytest.skip("emulated handlers are for one-GPU boxes")
     monkeypatch.setenv("SF_EMULATE_HANDLERS", "2")
+    monkeypatch.setenv("SF_LOOKAHEAD", "1")
     N = 33
     n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=13)
     perm = nd_perm_py(N, N, N)
