@@ -294,6 +294,7 @@ int sf_handlers_solve_resident_sym(const sf_float *Lsx_host, const sf_float *b, 
                                    const sf_long *Super, const sf_long *SuperMap, const sf_long *Lsip, const sf_long *Lsi,
                                    const sf_long *Lsxp, const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui);
 void sf_handlers_forget(const sf_float *Lsx_host);
+int64_t sf_handlers_replica_mismatches(const sf_float* Lsx_host); /* values of shared panels that differ bitwise between ranks (tests; -1: not a multi-handler factor) */
 int64_t sf_handlers_resident_solves(void);     /* how many solves were served from a resident factor so far (tests) */
 
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */

@@ -86,6 +86,8 @@ lib.sf_chol_plan_solve.argtypes = [C.c_void_p, c_double_p, c_double_p]
 lib.sf_chol_plan_solve.restype = C.c_int
 lib.sf_chol_plan_solve_distributed.argtypes = [C.c_void_p, C.c_void_p, c_double_p, c_double_p]
 lib.sf_chol_plan_solve_distributed.restype = C.c_int
+lib.sf_handlers_replica_mismatches.argtypes = [C.c_void_p]
+lib.sf_handlers_replica_mismatches.restype = C.c_int64
 lib.sf_handlers_resident_solves.argtypes = []
 lib.sf_handlers_resident_solves.restype = C.c_int64
 lib.sf_handlers_plan_builds.argtypes = [C.c_void_p, C.c_int]

@@ -285,12 +285,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // stay covered by the tests
     int64_t fuse_max = 32 * sf::GEMM_GRID;
     if (const char* env = getenv("SF_FUSE_MAX")) fuse_max = strtoll(env, nullptr, 10);
-    // LU: the look-ahead schedule adds the near part of a block's update on every rank separately (k_gemm's fp64 atomics: the order
-    // of the additions, hence the last bits, differ from rank to rank), and a threshold pivot decision taken on such a block could
-    // differ between the ranks of a group, whose copies of the panel must stay interchangeable.  Without it everything a chain
-    // reads is bit-identical inside the group (all-reduced sums; the step kernels add in a fixed order).  So LU keeps the in-line
-    // sums unless asked (SF_LOOKAHEAD=1, e.g. with pivoting off).
-    if (lu) p->lookahead = false;
+    // (The ranks of a group must keep bit-identical copies of a shared panel: an LU threshold pivot decision may not depend on a
+    // rank's own rounding.  Everything a chain reads is either an all-reduced sum or computed in a fixed order -- the step kernels,
+    // and the look-ahead schedule's replicated near parts, which run k_gemm with whole_tiles: one addition per target element.)
     if (const char* env = getenv("SF_LOOKAHEAD")) p->lookahead = atoi(env) != 0;      // 0: the round-1 schedule (tests cover both)
     // The sweep: one set of independent supernodes at a time -- phase 0: a level of the owned subtrees; phase 1: the top
     // supernodes of one level that share one group of ranks (ascending mask: every rank meets the sets it shares with
@@ -363,6 +360,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             if ((int64_t)gtasks.size() > g0) {
                 p->launches.push_back(Launch{4, g0, (int)(gtasks.size() - g0)});
                 p->launches.back().split = split && LS.share_cnt > 1;
+                p->launches.back().whole_tiles = shared && !split && LS.share_cnt > 1;      // replicated inside a group: reproducible
                 p->launches.back().share_idx = LS.share_idx; p->launches.back().share_cnt = LS.share_cnt;
                 p->launches.back().share_lo = LS.lo; p->launches.back().share_hi = LS.hi;
             }
@@ -906,6 +904,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         for (Launch& L : p->launches)
             if (L.kind == 2 || L.kind == 3 || L.kind == 4) { L.ticket = p->n_tickets; p->n_tickets += 8; }
         if (const char* env = getenv("SF_GEMM_DYNAMIC")) p->gemm_dynamic = atoi(env) != 0;
+        if (const char* env = getenv("SF_GEMM_WHOLE_TILES"))        // 0: replicated launches split tiles like the others (A/B only:
+            if (atoi(env) == 0)                                      // the ranks' copies of a shared panel then differ in the last bits)
+                for (Launch& L : p->launches) L.whole_tiles = false;
         // + 2 doubles: the GEMM stages row PAIRS with 16-byte loads and may touch 8 bytes past the last panel
         const size_t xb = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
@@ -1203,7 +1204,8 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                     u1 = L.share_hi >= 1.0 ? L.units : (uint32_t)((double)L.units * L.share_hi);
                 }
                 sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, u0, u1,
-                                L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, p->gemm_dynamic ? p->d_info + 1 + L.ticket : nullptr, st);
+                                L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, p->gemm_dynamic ? p->d_info + 1 + L.ticket : nullptr, st,
+                                (L.whole_tiles && !L.split) ? 1 : 0);
                 break;
             }
         }

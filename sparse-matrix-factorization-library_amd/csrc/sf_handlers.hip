@@ -485,8 +485,8 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
     const sf_long xs = plan->xsize, w = std::min<sf_long>(512, xs);
     const sf_long starts[3] = {0, std::max<sf_long>(0, xs / 2 - w / 2), xs - w};
     std::vector<double> dev((size_t)w);
-    // (a gathered factor: the ranks of a group hold copies of a shared panel that differ in the last bits -- each ran the chain with
-    // its own order of atomic additions -- and the host piece may come from another rank than the gathered one: compare to 1e-10)
+    // (a gathered factor: the host piece of a shared panel may come from another rank than the gathered one.  The ranks' copies are
+    // bit-identical by construction (whole_tiles, see plan_create) unless SF_GEMM_WHOLE_TILES=0 asked otherwise: compare to 1e-10)
     const bool exact = R.parts.empty();
     for (sf_long st : starts) {
         bool same = sf_chol_plan_get_factor_range(plan, st, st + w, dev.data()) == SF_OK;
@@ -513,6 +513,36 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
 
 int sf_handlers_solve_resident(const sf_float* Lsx_host, const sf_float* b, sf_float* x) {
     return sf_handlers_solve_resident_sym(Lsx_host, b, x, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// Test hook: how many values of the panels that several ranks store (the shared top supernodes of a multi-handler factorization)
+// differ BITWISE between a rank's copy and the first holder's.  0 is the invariant the LU pivot decisions rest on (plan_create);
+// -1: no multi-handler factor is registered for this host array.
+int64_t sf_handlers_replica_mismatches(const sf_float* Lsx_host) {
+    std::lock_guard<std::mutex> g(g_res_mu);
+    auto it = g_resident.find((const void*)Lsx_host);
+    if (it == g_resident.end() || it->second.parts.size() < 2) return -1;
+    const std::vector<sf_chol_plan*>& parts = it->second.parts;
+    const sf_chol_plan* P0 = parts[0];
+    int64_t bad = 0;
+    std::vector<double> a, b;
+    for (int64_t s = 0; s < P0->nsuper; ++s) {
+        const size_t len = (size_t)(P0->h_Lsip[s + 1] - P0->h_Lsip[s]) * (size_t)(P0->h_Super[s + 1] - P0->h_Super[s]);
+        const sf_chol_plan* first = nullptr;
+        for (sf_chol_plan* P : parts) {
+            if (P->h_XP[s] < 0) continue;
+            std::vector<double>& dst = first ? b : a;
+            dst.resize(len * (P->lu ? 2 : 1));
+            if (hipSetDevice(P->device) != hipSuccess ||
+                hipMemcpy(dst.data(), P->d_Lsx + P->h_XP[s], len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            if (P->lu && !P->u_alias &&
+                hipMemcpy(dst.data() + len, P->d_Lsx + P->xC + P->h_XP[s], len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            if (P->lu && P->u_alias) dst.resize(len);
+            if (!first) { first = P; continue; }
+            for (size_t i = 0; i < a.size(); ++i) bad += memcmp(&a[i], &b[i], sizeof(double)) != 0;
+        }
+    }
+    return bad;
 }
 
 int64_t sf_handlers_resident_solves(void) {

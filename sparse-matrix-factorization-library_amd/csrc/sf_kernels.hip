@@ -794,7 +794,7 @@ template <int MODE, bool DMA>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap, int* __restrict__ ticket) {
+       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap, int* __restrict__ ticket, int whole_tiles) {
     __shared__ int s_claim;
     __shared__ __attribute__((aligned(16))) double Ys[2][GEMM_BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Xs[2][GEMM_BK][LDS_LD];
@@ -830,9 +830,12 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
     int t0 = last_le_u32(kt_prefix, ntasks + 1, u_lo);
     if (kt_prefix[t0] < u_lo) ++t0;
     const int t1 = last_le_u32(kt_prefix, ntasks + 1, u_hi);          // tiles [t0, t1) lie inside [u_lo, u_hi)
-    const int R = (t1 > t0) ? (int)((uint32_t)(t1 - t0) / G) : 0;
+    // whole_tiles: every tile is multiplied over its full K range by ONE workgroup (the last round is partial, nothing is split by
+    // units), so each target element receives exactly one addition from this launch and the result does not depend on the order
+    // workgroups run in -- what a launch that several ranks execute redundantly needs (the ranks' copies must stay bit-identical)
+    const int R = (t1 > t0) ? (int)(((uint32_t)(t1 - t0) + (whole_tiles ? G - 1 : 0)) / G) : 0;
     const uint32_t head_end = (R > 0) ? kt_prefix[t0] : u_hi;
-    const uint32_t tail_beg = (R > 0) ? kt_prefix[t0 + R * (int)G] : u_hi;
+    const uint32_t tail_beg = (R > 0 && !whole_tiles) ? kt_prefix[t0 + R * (int)G] : u_hi;
 
     // ticket != nullptr: the rounds are DYNAMIC -- the workgroups of an XCD claim the tiles of that XCD's slots (the same
     // tiles as in the static deal, so a supertile still shares one L2) from the XCD's counter in the order they get free; tiles of
@@ -863,6 +866,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         if (rr >= R) { ph = 2; continue; }
         ti = t0 + rr * (int)G + (int)slot;
         ++rr;
+        if (ti >= t1) continue;                 // (whole_tiles: the last round is partial)
         u = kt_prefix[ti];
         u_end = kt_prefix[ti + 1];
     } else {
@@ -1770,7 +1774,7 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
 }
 
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st) {
+                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st, int whole_tiles) {
     if (ntasks <= 0 || u_hi <= u_lo) return;
     const uint32_t units = u_hi - u_lo;
     const uint32_t grid = units < (uint32_t)GEMM_GRID ? units : (uint32_t)GEMM_GRID;
@@ -1780,15 +1784,15 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
     const bool dma = e ? atoi(e) != 0 : true;
     if (dma) {
         if (mode == 1)
-            hipLaunchKernelGGL((k_gemm<1, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
+            hipLaunchKernelGGL((k_gemm<1, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
         else
-            hipLaunchKernelGGL((k_gemm<0, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
+            hipLaunchKernelGGL((k_gemm<0, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
         return;
     }
     if (mode == 1)
-        hipLaunchKernelGGL((k_gemm<1, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
+        hipLaunchKernelGGL((k_gemm<1, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
     else
-        hipLaunchKernelGGL((k_gemm<0, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket);
+        hipLaunchKernelGGL((k_gemm<0, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
 }
 
 }  // namespace sf

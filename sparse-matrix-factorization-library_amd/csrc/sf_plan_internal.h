@@ -31,6 +31,7 @@ struct Launch {
     double flops = 0;           // GEMM launches: algorithmic flops of the problems in this launch
     bool split = false;         // distributed top: this rank executes the units [share_lo, share_hi) x units of this launch
     int share_idx = 0, share_cnt = 1;
+    bool whole_tiles = false;   // GEMM launch executed in full by every rank of a group: no K-splitting, bit-identical results (see k_gemm)
     double share_lo = 0.0, share_hi = 1.0;      // = share_idx / share_cnt, (share_idx + 1) / share_cnt unless the set's shares are weighted
     int ticket = 0;             // k_step launches: index of the launch's task-claim counter (d_info[1 + ticket])
 };

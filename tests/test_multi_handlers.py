@@ -34,6 +34,7 @@ def _chol_case(oracle, N, nhandlers_expected):
         mi.analyze(common)
         C.memset(mi.c.Lsx, 0xff, 8 * sym.xsize)          # NaNs: every entry must be written by some rank's copy-back
         mi.factorize(common)
+        assert sf._lib.lib.sf_handlers_replica_mismatches(mi.c.Lsx) == 0      # shared panels: bit-identical on the ranks of a group
         got = mi.array("Lsx", sym.xsize).copy()
         assert not np.isnan(got[mask]).any()
         assert rel_err(got, ref * np.sqrt(scale), mask) <= TOL_FACTOR
@@ -168,12 +169,13 @@ def test_distributed_solve_with_the_factor_left_on_the_ranks(monkeypatch, method
 
 
 def test_lookahead_schedule_lu(oracle, monkeypatch):
-    """LU keeps the in-line sums by default (pivot decisions must not depend on a rank's own rounding, see plan_create);
-    SF_LOOKAHEAD=1 selects the look-ahead schedule for it -- same factor on this diagonally dominant matrix"""
+    """LU with the look-ahead schedule (the default): the ranks of a group must hold bit-identical copies of a shared panel --
+    threshold pivot decisions may not depend on a rank's own rounding -- so the replicated near parts run k_gemm without
+    K-splitting (whole_tiles).  Checked with the library's replica comparison, then the factor against the oracle"""
     if sf.device_count() != 1:
         pytest.skip("emulated handlers are for one-GPU boxes")
     monkeypatch.setenv("SF_EMULATE_HANDLERS", "2")
-    monkeypatch.setenv("SF_LOOKAHEAD", "1")
+    monkeypatch.delenv("SF_LOOKAHEAD", raising=False)
     N = 33
     n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=13)
     perm = nd_perm_py(N, N, N)
@@ -183,6 +185,7 @@ def test_lookahead_schedule_lu(oracle, monkeypatch):
     mi.set_perm(perm)
     mi.analyze(common)
     mi.factorize(common)
+    assert sf._lib.lib.sf_handlers_replica_mismatches(mi.c.Lsx) == 0
     assert mi.validate() <= TOL_RESIDUAL
     S = sf.analyze(n, Cp, Ci, Cx, perm, 8 << 30, "lu", False)
     assert np.diff(S.Super).max() > 1024
