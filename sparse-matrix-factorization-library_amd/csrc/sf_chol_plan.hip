@@ -264,6 +264,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         // keep tiles that contain at least one element with ci >= cj
                         if ((tm + 1) * sf::GEMM_BM - 1 < tn * sf::GEMM_BN) continue;
                         gtasks.push_back(GemmTask{prob_id, (uint16_t)tm, (uint16_t)tn, (uint32_t)k0, (uint32_t)std::min(gemm_slice, nkt_all - k0)});
+                        p->flops_tiles += 2.0 * sf::GEMM_BM * sf::GEMM_BN * sf::GEMM_BK * (double)std::min(gemm_slice, nkt_all - k0);
                     }
     };
 
@@ -542,7 +543,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                                 if ((tm + 1) * sf::SU_TM - 1 >= tn * sf::SU_TN)
                                     stasks.push_back(GemmTask{(int32_t)probs.size() - 1, (uint16_t)tm, (uint16_t)tn, 0u, 0u});
                     } else {
-                        add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K);
+                        { const double t0f = p->flops_tiles; add_tiles((int32_t)probs.size() - 1, g.M, g.N, g.K); p->flops_tiles_update += p->flops_tiles - t0f; }
                     }
                 }
                 // executed flops of the tiles' useful part: Cholesky dn(dn+1)dk + 2 dm dn dk; LU twice minus the
@@ -1764,6 +1765,8 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
     if (k == "last_small_update_ms") return p->last_kind_ms[6];
     if (k == "flops_update_small") return p->flops_update_small;
     if (k == "flops_outer_gemm") return p->flops_outer_gemm;
+    if (k == "flops_tiles") return p->flops_tiles;
+    if (k == "flops_tiles_update") return p->flops_tiles_update;
     return -1;
 }
 

@@ -1145,44 +1145,54 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         // rows beyond b / nrows are clamped: their values only reach accumulator entries replaced by the padding below
         const double* __restrict__ xp = Lsx + t.xpanel + t.diag + (int64_t)t.J * ld + ((prow < b) ? prow : 0);
         const double* __restrict__ yp = Lsx + t.panel + t.row0 + (int64_t)(t.J + fk) * ld + min(16 * wave + fr, nrows - 1);
-        double2_t rx[4];
-        double fy[2][8];
-        auto load_x = [&](int h) {
+        // K is short and most launches are a few hundred workgroups (one wave per SIMD): the loop lives on the distance of its
+        // prefetches, not on occupancy.  Y fragments: a ring of 4 HALF chunks (16 k each) in registers, every half chunk loaded
+        // 1.5 chunks before its use; X: two register sets, loaded 3 chunks ahead of their use and stored to the other LDS buffer
+        // one chunk ahead.
+        const int nhalf = 2 * nch;
+        double2_t rx[2][4];
+        double fy[4][4];
+        auto load_x = [&](int sel, int h) __attribute__((always_inline)) {
             const int hc = min(h, nch - 1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const double2_t*>(xp + (int64_t)(hc * ST_KC + pk0 + 8 * q) * ld);
+            for (int q = 0; q < 4; ++q) rx[sel][q] = *reinterpret_cast<const double2_t*>(xp + (int64_t)(hc * ST_KC + pk0 + 8 * q) * ld);
         };
-        auto store_x = [&](int buf) {
+        auto store_x = [&](int buf, int sel) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2_t*>(&Xs[buf][pk0 + 8 * q][prow]) = rx[q];
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2_t*>(&Xs[buf][pk0 + 8 * q][prow]) = rx[sel][q];
         };
-        auto load_y = [&](int bufi, int h) {
-            const int hc = min(h, nch - 1);
+        auto load_y = [&](int slot, int hh) __attribute__((always_inline)) {          // half chunk hh -> ring slot
+            const int hc = min(hh, nhalf - 1);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) fy[bufi][kk] = yp[(int64_t)(hc * ST_KC + 4 * kk) * ld];
+            for (int kk = 0; kk < 4; ++kk) fy[slot][kk] = yp[(int64_t)(hc * (ST_KC / 2) + 4 * kk) * ld];
         };
-        auto compute = [&](int buf, int h) {
+        // chunk h (h & 1 == par): X from Xs[par], Y from the ring slots 2 par, 2 par + 1; stores chunk h + 1 (register set
+        // par ^ 1) and reloads that set with chunk h + 3; half chunks 2 h + 3 and 2 h + 4 are requested on the way
+        auto compute = [&](int par, int h) __attribute__((always_inline)) {
+            load_y((2 * par + 3) & 3, 2 * h + 3);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 double a[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = Xs[buf][4 * kk + fk][16 * q + fr];
-                if (kk == 0) store_x(buf ^ 1);
-                if (kk == 1) load_x(h + 2);
+                for (int q = 0; q < 4; ++q) a[q] = Xs[par][4 * kk + fk][16 * q + fr];
+                if (kk == 0) store_x(par ^ 1, par ^ 1);
+                if (kk == 1) load_x(par ^ 1, h + 3);
+                if (kk == 4) load_y(2 * par, 2 * h + 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], fy[buf][kk], acc[q], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], fy[2 * par + (kk >> 2)][kk & 3], acc[q], 0, 0, 0);
             }
         };
-        load_x(0);
+        load_x(0, 0);
+        load_x(1, 1);
         load_y(0, 0);
-        store_x(0);
+        load_y(1, 1);
+        load_y(2, 2);
+        store_x(0, 0);
+        load_x(0, 2);
         __syncthreads();
-        load_x(1);
         for (int hp = 0; hp < nhp; ++hp) {
-            load_y(1, 2 * hp + 1);
             compute(0, 2 * hp);
             __syncthreads();
-            load_y(0, 2 * hp + 2);
             compute(1, 2 * hp + 1);
             __syncthreads();
         }

@@ -198,6 +198,7 @@ struct sf_chol_plan {
     std::vector<Launch> launches;
     int nlevels = 0;
     int64_t n_gemm_tasks = 0, n_pairs = 0;
+    double flops_tiles = 0, flops_tiles_update = 0;   // MFMA flops the GEMM tiles issue (full 128 x 128 x 16 steps): all launches / Schur updates
     double flops_update_small = 0;      // part of flops_update done by k_update_small (K <= SU_MAXK)
     double flops_exec = 0, flops_update = 0, scatter_elems = 0, flops_panel_gemm = 0, flops_outer_gemm = 0;
     size_t bytes_device = 0;
