@@ -806,7 +806,25 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
 
     int rc = SF_OK;
     do {
-        if (hipStreamCreate(&p->stream) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess ||
+        // The plan's streams are HIGH-PRIORITY streams: the runtime multiplexes all streams of one priority over a few hardware
+        // queues (4 by default), and the copy-back workers bring six streams of their own.  Whenever the compute stream landed on
+        // a hardware queue together with one of those, its kernels queued up behind the worker's event waits and copies and a
+        // struct call took 0.89 s instead of 0.555 s (bimodal, about one call in four; always with GPU_MAX_HW_QUEUES=2, never
+        // with 12 -- `tools/struct_mode_ab.sh`).  High-priority streams get hardware queues of their own.  SF_STREAM_PRIORITY=0:
+        // ordinary streams.
+        int prio_least = 0, prio_greatest = 0;
+        bool prio = true;
+        if (const char* env = getenv("SF_STREAM_PRIORITY")) prio = atoi(env) != 0;
+        if (prio && (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess || prio_greatest >= prio_least)) {
+            (void)hipGetLastError();
+            prio = false;
+        }
+        auto new_stream = [&](hipStream_t* st, unsigned flags) {
+            if (prio && hipStreamCreateWithPriority(st, flags, prio_greatest) == hipSuccess) return true;
+            (void)hipGetLastError();
+            return hipStreamCreateWithFlags(st, flags) == hipSuccess;
+        };
+        if (!new_stream(&p->stream, hipStreamDefault) || hipEventCreate(&p->ev0) != hipSuccess ||
             hipEventCreate(&p->ev1) != hipSuccess || hipEventCreate(&p->ev_s0) != hipSuccess ||
             hipEventCreate(&p->ev_s1) != hipSuccess) { rc = SF_ERR_HIP; break; }
         p->dl_events.assign(p->dl_ev_ready.size(), nullptr);
@@ -869,7 +887,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             p->scratch_elems = mx;
             if (hipMalloc((void**)&p->d_scratch, 2 * mx * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += 2 * mx * sizeof(double);
-            bool ok = hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) == hipSuccess;
+            bool ok = new_stream(&p->stream2, hipStreamNonBlocking);
             for (int k = 0; k < 2; ++k) {
                 ok = ok && hipEventCreateWithFlags(&p->ev_contrib[k], hipEventDisableTiming) == hipSuccess;
                 ok = ok && hipEventCreateWithFlags(&p->ev_reduced[k], hipEventDisableTiming) == hipSuccess;
@@ -1460,6 +1478,8 @@ int sf_chol_plan_validate(sf_chol_plan* p, sf_float* residual, sf_float* x_host)
 
 #include <sys/mman.h>
 #include <unistd.h>
+#include <sched.h>
+#include <cctype>
 
 static void dl_fail(sf_chol_plan* p, int code) {
     int expect = 0;
@@ -1477,7 +1497,64 @@ static double dl_now() {
     return t.tv_sec * 1e3 + t.tv_nsec / 1e6;
 }
 
+// The copy workers move the whole factor (30 GB at 128^3) from the pinned staging ring into the caller's pageable Lsx while the
+// factorization runs: ~55 GB/s of memcpy, which on a two-socket host is cheapest from the socket the device hangs on (the ring
+// lives there).  SF_DL_PIN=1 confines the workers to the CPUs of the device's NUMA node (hipDeviceAttributeHostNumaId or the PCI
+// device's sysfs entry), intersected with the affinity mask the process was given.  OFF by default: measured neutral on the
+// two-socket box of this project (profiles/r02_f_struct_slow_mode.txt, part 3 -- the slow calls seen there had another cause, see
+// the stream priorities in plan_create), and a library should not move its caller's threads around without being asked.
+static void dl_lookup_cpus(sf_chol_plan* p) {
+    p->dl_cpus_known = -1;
+    const char* pin_env = getenv("SF_DL_PIN");
+    if (!pin_env || atoi(pin_env) == 0) return;
+    int node = -1;
+    if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, p->device) != hipSuccess) { (void)hipGetLastError(); node = -1; }
+    if (node < 0) {                                              // older runtimes: the PCI device's own sysfs entry
+        char bdf[32] = {0}, path0[96];
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, p->device) == hipSuccess) {
+            for (char* q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);
+            snprintf(path0, sizeof path0, "/sys/bus/pci/devices/%s/numa_node", bdf);
+            if (FILE* f0 = fopen(path0, "r")) {
+                if (fscanf(f0, "%d", &node) != 1) node = -1;
+                fclose(f0);
+            }
+        } else (void)hipGetLastError();
+    }
+    if (getenv("SF_TRACE")) fprintf(stderr, "[sparseframe-hip]   device %d hangs on NUMA node %d\n", p->device, node);
+    if (node < 0) return;
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    char buf[4096];
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    for (char* q = buf; *q;) {                                   // "0-63,128-191"
+        char* e = nullptr;
+        const long a = strtol(q, &e, 10);
+        if (e == q) break;
+        long b = a;
+        if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); if (e == q) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) p->dl_cpus.push_back((int)c);
+        q = (*e == ',') ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    if (!p->dl_cpus.empty()) p->dl_cpus_known = 1;
+}
+
 static void dl_worker(sf_chol_plan* p, int w) {
+    if (p->dl_cpus_known == 1) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        for (int c : p->dl_cpus) CPU_SET(c, &set);
+        (void)sched_setaffinity(0, sizeof set, &set);            // this thread only; a failure leaves it where it was
+    }
+    struct CpuNote { sf_chol_plan* p; int w; ~CpuNote() { p->dl_last_cpu[w] = sched_getcpu(); } } note{p, w};
     if (hipSetDevice(p->device) != hipSuccess) { dl_fail(p, SF_ERR_HIP); return; }
     hipStream_t ws = p->dl_streams[w];
     const size_t np = p->dl_pieces.size();
@@ -1544,6 +1621,7 @@ static void dl_worker(sf_chol_plan* p, int w) {
 int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     if (!p || !host_out || p->dl_active) return SF_ERR_ARG;
     HIP_TRY(hipSetDevice(p->device));
+    if (p->dl_cpus_known == 0) dl_lookup_cpus(p);
     if (!p->h_ring) {
         const size_t rb = (size_t)p->dl_workers * 2 * p->dl_slot * sizeof(double);
         HIP_TRY(hipHostMalloc((void**)&p->h_ring, rb, hipHostMallocDefault));

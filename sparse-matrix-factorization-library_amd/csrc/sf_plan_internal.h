@@ -108,6 +108,9 @@ struct sf_chol_plan {
     int64_t dl_slot = DL_SLOT_DEFAULT;
     int dl_workers = DL_WORKERS_DEFAULT;
     hipStream_t dl_streams[DL_WORKERS_MAX] = {};
+    int dl_cpus_known = 0;                      // 0 not looked up yet, 1 dl_cpus holds the CPUs of the device's NUMA node, -1 none / disabled
+    std::vector<int> dl_cpus;
+    int dl_last_cpu[DL_WORKERS_MAX] = {};       // CPU each copy worker finished its last download on (SF_TRACE)
     hipEvent_t dl_done[DL_WORKERS_MAX][2] = {};
     double last_to_host_ms = 0;                 // wall time of the last sf_chol_plan_factorize_to_host
     std::vector<std::thread> dl_threads;
