@@ -63,7 +63,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_fill};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -711,6 +711,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         L.units = (uint32_t)run;
     }
 
+    std::vector<sf::FillTile> fill_tiles;
     // ---------------- download schedule (sf_chol_plan_factorize_to_host) ----------------
     // Block columns in host order, merged while contiguous in the host layout (Cholesky: and in the device layout) up to
     // one staging slot, larger runs cut into slot-sized pieces.  Top panels of a sharded plan are identical on every
@@ -725,10 +726,58 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         std::vector<uint32_t> run_mask;
         int last_phase = -2;
         uint32_t last_mask = 0;
+        // LU: the reference keeps one packed panel per supernode, column j = [ L11 \ U11 (nscol) | L21 | U12^T ] (L:2514-2517), the
+        // device an L panel and a U^T panel.  DIRECT form (default): the pieces are whole columns; the compute stream writes U11 into
+        // the (unused) upper triangle of the L panel's diagonal block before a piece's event (k_lu_fill_u11), the L and U^T runs
+        // travel as they are and the copy worker interleaves them column by column.  SF_DL_LU_PACK=1 (and any matrix with a
+        // packed column longer than a staging slot): the older form, a gather kernel per piece on the worker's stream -- which has
+        // to find free CUs next to the factorization's persistent kernels and made the LU struct call 2x its resident step.
+        bool lu_direct = lu;
+        if (const char* env = getenv("SF_DL_LU_PACK"))
+            if (atoi(env) != 0) lu_direct = false;
+        for (sf_long s = 0; s < nsuper && lu_direct; ++s)
+            if (XP[s] >= 0 && 2 * (Lsip[s + 1] - Lsip[s]) - (Super[s + 1] - Super[s]) > DL_SLOT) lu_direct = false;
+        p->dl_lu_direct = lu_direct;
         for (sf_long s = 0; s < nsuper; ++s) {
             if (XP[s] < 0) continue;
             const int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
             const int64_t hld = lu ? 2 * nsrow - nscol : nsrow;
+            if (lu_direct) {
+                const int64_t cntL = nsrow * nscol;
+                if (2 * cntL <= DL_SLOT) {                       // a whole supernode, merged with its neighbours while they fit a slot
+                    size_t ready = 0;
+                    for (int64_t jo = 0; jo * sf::OUTER_NB < nscol; ++jo) ready = std::max(ready, blk_ready[blk_first[s] + jo]);
+                    DlPiece pc{XP[s], Lsxp[s], nscol * hld, ready, 0};
+                    pc.s0 = (int32_t)s; pc.s1 = (int32_t)s + 1; pc.dev_count = cntL;
+                    const bool can_merge = !runs.empty() && runs.back().s0 >= 0 && runs.back().ld == 0 && runs.back().s1 == (int32_t)s &&
+                                           last_phase == p->phase[s] && last_mask == gmask[s] &&
+                                           runs.back().dev_off + runs.back().dev_count == pc.dev_off &&
+                                           runs.back().host_off + runs.back().count == pc.host_off &&
+                                           2 * (runs.back().dev_count + cntL) <= DL_SLOT;
+                    if (can_merge) {
+                        runs.back().count += pc.count;
+                        runs.back().dev_count += cntL;
+                        runs.back().s1 = (int32_t)s + 1;
+                        runs.back().ready = std::max(runs.back().ready, pc.ready);
+                    } else {
+                        pc.ev = p->phase[s];
+                        runs.push_back(pc);
+                        run_mask.push_back(gmask[s]);
+                    }
+                } else {
+                    for (int64_t jo = 0; jo * sf::OUTER_NB < nscol; ++jo) {     // block columns, cut to slot size below
+                        const int64_t J = jo * sf::OUTER_NB, w = std::min<int64_t>(sf::OUTER_NB, nscol - J);
+                        DlPiece pc{XP[s] + J * nsrow, Lsxp[s] + J * hld, w * hld, blk_ready[blk_first[s] + jo], 0};
+                        pc.s0 = (int32_t)s; pc.s1 = (int32_t)s + 1; pc.j0 = J; pc.ncols = w; pc.ld = nsrow; pc.dev_count = w * nsrow;
+                        pc.ev = p->phase[s];
+                        runs.push_back(pc);
+                        run_mask.push_back(gmask[s]);
+                    }
+                }
+                last_phase = p->phase[s];
+                last_mask = gmask[s];
+                continue;
+            }
             for (int64_t jo = 0; jo * sf::OUTER_NB < nscol; ++jo) {
                 const int64_t J = jo * sf::OUTER_NB, w = std::min<int64_t>(sf::OUTER_NB, nscol - J);
                 DlPiece pc{XP[s] + J * nsrow, Lsxp[s] + J * hld, w * hld, blk_ready[blk_first[s] + jo], 0};
@@ -763,6 +812,18 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 const int64_t seq = seen_by_mask[k].second++;
                 if ((int)(seq % __builtin_popcount(m)) != group_idx(m)) continue;
             }
+            if (r.s0 >= 0) {        // LU, direct form
+                if (r.ld == 0) { p->dl_pieces.push_back(r); p->dl_pieces.back().ev = 0; continue; }
+                const int64_t hld = 2 * r.ld - (Super[r.s0 + 1] - Super[r.s0]), cper = std::max<int64_t>(1, DL_SLOT / hld);
+                for (int64_t c = 0; c < r.ncols; c += cper) {
+                    DlPiece q = r;
+                    q.ev = 0;
+                    q.j0 = r.j0 + c; q.ncols = std::min(cper, r.ncols - c);
+                    q.dev_off = r.dev_off + c * r.ld; q.host_off = r.host_off + c * hld; q.count = q.ncols * hld; q.dev_count = q.ncols * r.ld;
+                    p->dl_pieces.push_back(q);
+                }
+                continue;
+            }
             if (r.ld > 0) {         // 2-D piece: cut by whole columns
                 const int64_t rows = r.ld - r.skip, cper = std::max<int64_t>(1, DL_SLOT / std::max<int64_t>(rows, 1));
                 if (rows > DL_SLOT) {       // one column longer than a slot (never with the default 32 MiB slot): plain pieces
@@ -784,6 +845,21 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         for (DlPiece& pc : p->dl_pieces) {
             if (p->dl_ev_ready.empty() || p->dl_ev_ready.back() != pc.ready) p->dl_ev_ready.push_back(pc.ready);
             pc.ev = (int)p->dl_ev_ready.size() - 1;
+        }
+        if (lu_direct) {            // the U11 fill tiles of every piece, grouped by the piece's event
+            std::vector<std::vector<sf::FillTile>> by_ev(p->dl_ev_ready.size());
+            for (const DlPiece& pc : p->dl_pieces)
+                for (int32_t s = pc.s0; s < pc.s1; ++s) {
+                    const int32_t nscol = (int32_t)(Super[s + 1] - Super[s]), nsrow = (int32_t)(Lsip[s + 1] - Lsip[s]);
+                    const int32_t cb = pc.ld > 0 ? (int32_t)pc.j0 : 0, ce = pc.ld > 0 ? (int32_t)(pc.j0 + pc.ncols) : nscol;
+                    for (int32_t c0 = cb / 64 * 64; c0 < ce; c0 += 64)
+                        for (int32_t r0 = 0; r0 <= c0; r0 += 64) by_ev[pc.ev].push_back(sf::FillTile{XP[s], nsrow, r0, c0, cb, ce});
+                }
+            p->fill_first.assign(1, 0);
+            for (const auto& v : by_ev) {
+                fill_tiles.insert(fill_tiles.end(), v.begin(), v.end());
+                p->fill_first.push_back((int64_t)fill_tiles.size());
+            }
         }
     }
 
@@ -880,6 +956,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         if (lu || p->partial) {
             if ((rc = upload(&p->d_Xp, XP, &p->bytes_device))) break;
+        }
+        if (!fill_tiles.empty()) {
+            const size_t fb = fill_tiles.size() * sizeof(sf::FillTile);
+            if (hipMalloc(&p->d_fill, fb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            if (hipMemcpy(p->d_fill, fill_tiles.data(), fb, hipMemcpyHostToDevice) != hipSuccess) { rc = SF_ERR_HIP; break; }
+            p->bytes_device += fb;
         }
         if (!p->segments.empty()) {
             int64_t mx = 1;
@@ -1128,6 +1210,12 @@ int sf_chol_plan_sync(sf_chol_plan* p) {
 static hipError_t dl_publish(sf_chol_plan* p, size_t done) {
     size_t k = p->dl_next_ev;
     while (k < p->dl_ev_ready.size() && p->dl_ev_ready[k] <= done) {
+        if (p->dl_lu_direct && p->d_fill && k + 1 < p->fill_first.size()) {
+            sf::launch_lu_fill_u11((const sf::FillTile*)p->d_fill + p->fill_first[k], p->fill_first[k + 1] - p->fill_first[k],
+                                   p->d_Lsx, p->d_Lsx + p->xC, p->stream);
+            const hipError_t ef = hipGetLastError();
+            if (ef != hipSuccess) return ef;
+        }
         const hipError_t e = hipEventRecord(p->dl_events[k], p->stream);
         if (e != hipSuccess) return e;
         ++k;
@@ -1567,7 +1655,26 @@ static void dl_worker(sf_chol_plan* p, int w) {
         if (hipEventSynchronize(p->dl_done[w][sl]) != hipSuccess) return false;
         if (!p->dl_trace.empty()) p->dl_trace[3 * k + 1] = dl_now() - p->dl_t0;
         const double* ring = p->h_ring + ((int64_t)w * 2 + sl) * DL_SLOT;
-        if (pc.ld > 0) {
+        if (pc.s0 >= 0) {
+            // LU, direct form: ring = [ L run | U^T run ]; column j of the reference panel = L column (nsrow) followed by rows
+            // [nscol, nsrow) of the U^T column
+            const double* rl = ring;
+            const double* ru = ring + pc.dev_count;
+            for (int32_t s = pc.s0; s < pc.s1; ++s) {
+                const int64_t nscol = p->h_Super[s + 1] - p->h_Super[s], nsrow = p->h_Lsip[s + 1] - p->h_Lsip[s];
+                const int64_t nb = nsrow - nscol, lda = nsrow + nb;
+                const int64_t j0 = pc.ld > 0 ? pc.j0 : 0, nc = pc.ld > 0 ? pc.ncols : nscol;
+                double* dst = p->dl_host + p->h_Lsxp[s] + j0 * lda;
+                // 2-D U part (one supernode): nb values per column; whole panels: full columns, the first nscol rows skipped
+                const int64_t ustride = pc.ld > 0 ? nb : nsrow, uskip = pc.ld > 0 ? 0 : nscol;
+                for (int64_t c = 0; c < nc; ++c) {
+                    memcpy(dst + c * lda, rl + c * nsrow, (size_t)nsrow * sizeof(double));
+                    if (nb > 0) memcpy(dst + c * lda + nsrow, ru + c * ustride + uskip, (size_t)nb * sizeof(double));
+                }
+                rl += nc * nsrow;
+                ru += nc * ustride;
+            }
+        } else if (pc.ld > 0) {
             const int64_t rows = pc.ld - pc.skip;
             for (int64_t c = 0; c < pc.ncols; ++c) {
                 double* col = p->dl_host + pc.host_off + c * pc.ld;
@@ -1595,6 +1702,26 @@ static void dl_worker(sf_chol_plan* p, int w) {
         double* hslot = p->h_ring + ((int64_t)w * 2 + slot) * DL_SLOT;
         bool ok = hipStreamWaitEvent(ws, p->dl_events[pc.ev], 0) == hipSuccess;
         const double* src = p->d_Lsx + pc.dev_off;
+        if (pc.s0 >= 0) {
+            // LU, direct form: the L run as it is; the U^T run as it is (whole supernodes) or rows [nscol, nsrow) of its columns
+            const double* usrc = src + p->xC;
+            ok = ok && hipMemcpyAsync(hslot, src, (size_t)pc.dev_count * sizeof(double), hipMemcpyDeviceToHost, ws) == hipSuccess;
+            if (pc.ld > 0) {
+                const int64_t nscol = p->h_Super[pc.s0 + 1] - p->h_Super[pc.s0], nb = pc.ld - nscol;
+                if (nb > 0)
+                    ok = ok && hipMemcpy2DAsync(hslot + pc.dev_count, (size_t)nb * sizeof(double), usrc + nscol, (size_t)pc.ld * sizeof(double),
+                                                (size_t)nb * sizeof(double), (size_t)pc.ncols, hipMemcpyDeviceToHost, ws) == hipSuccess;
+            } else {
+                ok = ok && hipMemcpyAsync(hslot + pc.dev_count, usrc, (size_t)pc.dev_count * sizeof(double), hipMemcpyDeviceToHost, ws) == hipSuccess;
+            }
+            ok = ok && hipEventRecord(p->dl_done[w][slot], ws) == hipSuccess;
+            if (ok && prev < np) ok = drain(prev, prev_slot);
+            if (!ok) { dl_fail(p, SF_ERR_HIP); return; }
+            prev = k;
+            prev_slot = slot;
+            slot ^= 1;
+            continue;
+        }
         if (ok && p->lu) {
             double* dslot = p->d_ring + ((int64_t)w * 2 + slot) * DL_SLOT;
             sf::launch_pack_lu(p->d_Super, p->d_Lsip, p->d_Xp, p->d_Lsxp, (int32_t)p->nsuper, p->d_Lsx, p->d_Lsx + p->xC,
@@ -1625,7 +1752,7 @@ int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     if (!p->h_ring) {
         const size_t rb = (size_t)p->dl_workers * 2 * p->dl_slot * sizeof(double);
         HIP_TRY(hipHostMalloc((void**)&p->h_ring, rb, hipHostMallocDefault));
-        if (p->lu) {
+        if (p->lu && !p->dl_lu_direct) {
             HIP_TRY(hipMalloc((void**)&p->d_ring, rb));
             p->bytes_device += rb;
         }

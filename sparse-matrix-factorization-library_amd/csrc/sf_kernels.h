@@ -113,6 +113,11 @@ void launch_potrf(const PotrfTask* tasks, int ntasks, double* Lsx, int* info, hi
 void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shift, int* info, PivotCtl pc, hipStream_t st);
 // LU: gather the (L, U^T) panel pairs into the reference's (2*nsrow - nscol) x nscol panels (LU/Source/SparseFrame.c:2514-2517):
 // values [e_begin, e_end) of that layout -> out[0 .. e_end - e_begin)
+// LU download without a gather kernel: PL(R, j) <- PU(j, R) for R <= j inside a supernode's diagonal block, i.e. the L panel
+// receives the reference's packed L11 \ U11 (L:2514-2517).  One workgroup per 64 x 64 tile: rows [r0, r0 + 64), columns
+// [max(c0, cb), min(c0 + 64, ce)), transposed through LDS.  Nothing reads that part of an L panel (the solves mask it by index).
+struct FillTile { int64_t xp; int32_t nsrow, r0, c0, cb, ce; };
+void launch_lu_fill_u11(const FillTile* tiles, int64_t ntiles, double* PL, const double* PU, hipStream_t st);
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
                     const double* PL, const double* PU, double* out, int64_t e_begin, int64_t e_end, hipStream_t st);
 // pivinv != nullptr (LU with pivoting): the unit tasks (U^T rows) permute their columns by the block's interchanges first

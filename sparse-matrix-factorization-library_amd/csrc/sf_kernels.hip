@@ -292,6 +292,34 @@ void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp
                        Super, Lsip, Xp, RefXp, nsuper, PL, PU, out, e_begin, e_end);
 }
 
+__global__ void __launch_bounds__(256)
+k_lu_fill_u11(const FillTile* __restrict__ tiles, double* __restrict__ PL, const double* __restrict__ PU) {
+    __shared__ double tile[64][65];
+    const FillTile t = tiles[blockIdx.x];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int jlo = max(t.c0, t.cb), jhi = min(t.c0 + 64, t.ce);
+    {
+        const int j = t.c0 + tx;                    // consecutive lanes: consecutive rows of the U^T panel
+        for (int rr = ty; rr < 64; rr += 4) {
+            const int R = t.r0 + rr;
+            if (j >= jlo && j < jhi && R <= j) tile[rr][tx] = PU[t.xp + j + (int64_t)R * t.nsrow];
+        }
+    }
+    __syncthreads();
+    {
+        const int R = t.r0 + tx;                    // consecutive lanes: consecutive rows of the L panel
+        for (int jj = ty; jj < 64; jj += 4) {
+            const int j = t.c0 + jj;
+            if (j >= jlo && j < jhi && R <= j) PL[t.xp + R + (int64_t)j * t.nsrow] = tile[tx][jj];
+        }
+    }
+}
+
+void launch_lu_fill_u11(const FillTile* tiles, int64_t ntiles, double* PL, const double* PU, hipStream_t st) {
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_lu_fill_u11, dim3((unsigned)ntiles), dim3(256), 0, st, tiles, PL, PU);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // X <- X * D^{-T} for a tile of rows, D = lower-triangular b x b block already factored.
 // One row per lane (rows are contiguous in memory: coalesced 8-byte accesses per column).

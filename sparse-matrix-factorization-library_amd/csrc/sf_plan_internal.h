@@ -78,7 +78,10 @@ static inline int upload(T** dptr, const std::vector<T>& h, size_t* bytes_total)
 // the host layout (and, for Cholesky, in the device layout), at most DL_SLOT doubles; it may be copied once launch
 // `ready` - 1 has completed (event `ev`).  Pieces are sorted by `ready`.
 constexpr int64_t DL_SLOT_DEFAULT = (int64_t)4 << 20;   // doubles per staging slot (32 MiB)
-constexpr int DL_WORKERS_DEFAULT = 6;                   // copy workers: own HIP stream + 2 pinned slots each
+constexpr int DL_WORKERS_DEFAULT = 4;                   // copy workers: own HIP stream + 2 pinned slots each.  4 = the number of hardware
+                                                        // queues the runtime gives the ordinary-priority streams: with 6 two pairs of
+                                                        // workers share a queue and the struct call at 128^3 takes 553-603 ms instead of
+                                                        // 552-568 (profiles/r02_f_struct_slow_mode.txt, part 5)
 constexpr int DL_WORKERS_MAX = 16;                      // SF_DL_WORKERS / SF_DL_SLOT_MB (read at plan creation) tune both
 struct DlPiece {
     int64_t dev_off, host_off, count;   // doubles; LU: dev_off unused (the piece is packed from the (L, U^T) panels)
@@ -88,6 +91,12 @@ struct DlPiece {
     // the device either), so only rows [skip, ld) of each of the `ncols` columns cross PCIe (count = ncols * (ld - skip), a 2-D
     // copy) and the host side zero-fills the prefixes.  ld == 0: a plain contiguous piece.
     int64_t skip = 0, ld = 0, ncols = 0;
+    // LU (direct form, no pack kernel): the piece is the columns [j0, j0 + ncols) of supernode s0 (s1 == s0 + 1, ld = nsrow: the
+    // L part is one contiguous run of the L panel, the U part -- rows [nscol, nsrow) of the same columns of the U^T panel -- a 2-D
+    // copy) or the whole supernodes [s0, s1) (ld == 0: both panels' runs copied as they are, dev_count doubles each); the copy
+    // worker interleaves the columns into the reference layout (L:2514-2517).  s0 < 0: not an LU-direct piece.
+    int32_t s0 = -1, s1 = -1;
+    int64_t j0 = 0, dev_count = 0;
 };
 
 struct sf_comm;      // one rank's end of a multi-GPU group (sf_multi.hip)
@@ -108,6 +117,12 @@ struct sf_chol_plan {
     int64_t dl_slot = DL_SLOT_DEFAULT;
     int dl_workers = DL_WORKERS_DEFAULT;
     hipStream_t dl_streams[DL_WORKERS_MAX] = {};
+    // LU direct download: before a piece's event is recorded, the upper triangle (with the diagonal) of its columns' part of the
+    // supernode's diagonal block is filled into the L panel from the U^T panel (k_lu_fill_u11), so that the L panel holds the
+    // reference's packed L11 \ U11 and the download needs no gather kernel
+    bool dl_lu_direct = false;
+    void* d_fill = nullptr;                     // sf::FillTile[], grouped by download event
+    std::vector<int64_t> fill_first;            // tiles of event k: [fill_first[k], fill_first[k + 1])
     int dl_cpus_known = 0;                      // 0 not looked up yet, 1 dl_cpus holds the CPUs of the device's NUMA node, -1 none / disabled
     std::vector<int> dl_cpus;
     int dl_last_cpu[DL_WORKERS_MAX] = {};       // CPU each copy worker finished its last download on (SF_TRACE)

@@ -276,3 +276,43 @@ def test_lu_struct_entry_points_end_to_end(oracle, tmp_path):
     assert rel_err(mi.array("Lsx", S.xsize).copy(), ref) <= TOL_FACTOR
     mi.cleanup()
     common.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["direct", "direct-small-slots", "pack"])
+def test_lu_struct_copy_back_forms(oracle, monkeypatch, form):
+    """The LU factor's way back to the host, compared value by value with the oracle's packed panels (L:2514-2517):
+    direct            -- U11 filled into the L panel's upper triangle on the compute stream (k_lu_fill_u11), the L and U^T runs
+                         copied as they are, the copy workers interleave the columns (default);
+    direct-small-slots - the same with 1 MiB staging slots, so that this small matrix also has supernodes cut into column
+                         ranges (L run + 2-D copy of the U^T rows below the diagonal block) as the big ones of 79^3 / 110^3 are;
+    pack              -- the older gather kernel per piece (SF_DL_LU_PACK=1)."""
+    if form == "pack":
+        monkeypatch.setenv("SF_DL_LU_PACK", "1")
+    if form == "direct-small-slots":
+        monkeypatch.setenv("SF_DL_SLOT_MB", "1")
+    N = 24
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=21)
+    perm = nd_perm_py(N, N, N)
+    common = sf.CommonInfo(dev_slot_size=4 << 30)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 4 << 30, "lu", False)
+    assert np.diff(S.Super).max() > 512            # a supernode of two outer blocks
+    ref, info, _ = oracle.lu_factorize(S)
+    assert info == 0
+    for scale in (1.0, 3.0):                         # second call: cached plan, the L panels' scratch triangles hold the last U11
+        mi = sf.LUMatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx * scale, symmetric=False)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        import ctypes as C
+        C.memset(mi.c.Lsx, 0xff, 8 * S.xsize)       # NaNs: every value must be written by the copy-back
+        mi.factorize(common)
+        got = mi.array("Lsx", S.xsize).copy()
+        assert not np.isnan(got).any()
+        # L is scale-invariant (unit lower), U scales: compare through the oracle on the scaled matrix
+        S2 = sf.analyze(n, Cp, Ci, Cx * scale, perm, 4 << 30, "lu", False)
+        ref2, info2, _ = oracle.lu_factorize(S2)
+        assert rel_err(got, ref2) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    common.close()
