@@ -212,6 +212,9 @@ int sf_comm_allreduce_sum(sf_comm *comm, void *device_buf, sf_long count, void *
 int sf_comm_destroy(sf_comm *comm);
 /* test hook: split the communicator (all ranks, one colour), all-reduce on the child, destroy it */
 int sf_comm_selftest_split(sf_comm *comm, void *device_buf, sf_long count, void *hip_stream);
+/* Optional, collective: create the sub-communicators of the plan's groups now and check the world and every group of this rank
+ * with one 8-byte sum (SF_ERR_HIP when a result is wrong) -- so that a launcher can still fall back when RCCL is not usable. */
+int sf_chol_plan_prepare_comm(sf_chol_plan *plan, sf_comm *comm);
 int sf_chol_plan_factorize_distributed(sf_chol_plan *plan, sf_comm *comm, sf_float *host_out /* or NULL */, int sync);
 /* The solve with a factor that stays distributed (mapped plans after sf_chol_plan_factorize_distributed; Cholesky and LU): b_host =
  * the whole right-hand side in the permuted numbering on every rank; every rank writes into x_host the entries it is responsible

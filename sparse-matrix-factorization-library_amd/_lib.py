@@ -146,6 +146,7 @@ lib.sf_comm_destroy.argtypes = [C.c_void_p]
 lib.sf_comm_destroy.restype = C.c_int
 lib.sf_comm_rank.argtypes = [C.c_void_p]
 lib.sf_comm_size.argtypes = [C.c_void_p]
+lib.sf_chol_plan_prepare_comm.argtypes = [C.c_void_p, C.c_void_p]
 lib.sf_chol_plan_factorize_distributed.argtypes = [C.c_void_p, C.c_void_p, c_double_p, C.c_int]
 lib.sf_chol_plan_factorize_distributed.restype = C.c_int
 lib.sf_lu_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9

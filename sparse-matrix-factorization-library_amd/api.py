@@ -224,6 +224,10 @@ class _ShardedPlanMixin:
         out = _dp(host_out) if host_out is not None else None
         check(lib.sf_chol_plan_factorize_distributed(self._h, comm._h, out, 1 if sync else 0), "sf_chol_plan_factorize_distributed")
 
+    def prepare_comm(self, comm):
+        """collective: sub-communicators of the plan's groups + one checked 8-byte sum per communicator (sf_chol_plan_prepare_comm)"""
+        check(lib.sf_chol_plan_prepare_comm(self._h, comm._h), "sf_chol_plan_prepare_comm")
+
     def solve_distributed(self, comm, b):
         """the solve with the factor left distributed (sf_chol_plan_solve_distributed): returns x with this rank's entries filled
         in (its subtrees' columns, the shared supernodes it leads) and zeros elsewhere -- the sum over the ranks is the solution"""

@@ -32,6 +32,14 @@
 
 #include "sf_plan_internal.h"
 
+// hipEventElapsedTime whose failure (an event that was never recorded) is expected and must not stay behind as the thread's
+// "last error": callers that poll hipGetLastError after their own launches (PyTorch does) would report it as theirs
+static bool elapsed_ms(float* ms, hipEvent_t a, hipEvent_t b) {
+    if (hipEventElapsedTime(ms, a, b) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 extern "C" {
 
 int sf_device_count(void) {
@@ -1198,7 +1206,9 @@ int sf_chol_plan_sync(sf_chol_plan* p) {
     int info = 0;
     HIP_TRY(hipMemcpy(&info, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
     float ms = 0;
-    if (hipEventElapsedTime(&ms, p->ev0, p->ev1) == hipSuccess) p->last_ms = ms;
+    // (a run driven segment by segment never records ev1: the call then fails, and the error must not stay behind as the thread's
+    // "last error" -- a caller that checks hipGetLastError after its own launches, as PyTorch does, would trip over it)
+    if (elapsed_ms(&ms, p->ev0, p->ev1)) p->last_ms = ms;
     if (p->lu) HIP_TRY(hipMemcpy(&p->last_perturbed, p->d_piv + 2 * std::max<int64_t>(p->n, 1), sizeof(int), hipMemcpyDeviceToHost));
     // 1: non-positive / zero pivot; 2: a fused step's flag wait timed out (internal error, never seen)
     p->last_status = (info & 2) ? SF_ERR_HIP : (info ? SF_ERR_NOT_POSDEF : SF_OK);
@@ -1328,12 +1338,12 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             for (double& v : p->last_kind_ms) v = 0;
         }
         float ms = 0;
-        if (first && !evs.empty() && hipEventElapsedTime(&ms, p->ev0, evs[0]) == hipSuccess) p->last_load_ms = ms;
+        if (first && !evs.empty() && elapsed_ms(&ms, p->ev0, evs[0])) p->last_load_ms = ms;
         FILE* dump = nullptr;
         if (const char* path = getenv("SF_PROFILE_DUMP")) dump = fopen(path, first ? "w" : "a");
         if (dump && first) fprintf(dump, "launch,kind,tasks,units,flops,ms\n");
         for (size_t k = 0; k + 1 < evs.size(); ++k) {
-            if (hipEventElapsedTime(&ms, evs[k], evs[k + 1]) != hipSuccess) continue;
+            if (!elapsed_ms(&ms, evs[k], evs[k + 1])) continue;
             if (kinds[k] == 3) p->last_update_ms += ms; else if (kinds[k] != 6) p->last_panel_ms += ms;
             p->last_kind_ms[kinds[k]] += ms;
             if (dump) {
@@ -2027,7 +2037,7 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     HIP_TRY(hipStreamSynchronize(st));
     if (sinfo) return SF_ERR_HIP;       // a bounded in-launch wait ran out (never seen)
     float ms = 0;
-    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) p->last_solve_ms = ms;
+    if (elapsed_ms(&ms, e0, e1)) p->last_solve_ms = ms;
     return SF_OK;
 }
 

@@ -305,6 +305,35 @@ int sf_comm_selftest_split(sf_comm* c, void* device_buf, sf_long count, void* st
     return (r == ncclSuccess && e == hipSuccess) ? SF_OK : SF_ERR_HIP;
 }
 
+// Everything a distributed run of `p` needs from `comm`, done up front and checked: the sub-communicators of the plan's groups
+// (ncclCommSplit) and ONE 8-byte sum on the world and on every group this rank belongs to, whose result must be the group's
+// size.  Collective (every rank of `comm`, with its own plan of the same factorization).  A launcher calls it right after
+// creating plan and communicator, so that a broken RCCL setup shows up as an error code there -- where falling back to another
+// path is still possible -- and not in the middle of the first factorization.
+int sf_chol_plan_prepare_comm(sf_chol_plan* p, sf_comm* comm) {
+    if (!p || !comm || comm->nranks != p->nranks || comm->rank != p->rank) return SF_ERR_ARG;
+    int rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size());
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(double)));
+    std::vector<sf_comm*> cs{comm};
+    for (uint32_t m : p->all_masks)                  // ascending masks: every rank meets the groups it shares with another in one order
+        if (sf_comm* g = group_comm(comm, m))
+            if (g != comm && ((m >> comm->rank) & 1u) && std::find(cs.begin(), cs.end(), g) == cs.end()) cs.push_back(g);
+    for (sf_comm* c : cs) {
+        const double one = 1.0;
+        double got = 0.0;
+        if (hipMemcpyAsync(d, &one, sizeof one, hipMemcpyHostToDevice, p->stream) != hipSuccess) { rc = SF_ERR_HIP; break; }
+        if ((rc = sf_comm_allreduce_sum(c, d, 1, p->stream))) break;
+        if (hipMemcpyAsync(&got, d, sizeof got, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+            hipStreamSynchronize(p->stream) != hipSuccess) { rc = SF_ERR_HIP; break; }
+        if (got != (double)c->nranks) { rc = SF_ERR_HIP; break; }
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int sf_comm_rank(const sf_comm* c) { return c ? c->rank : -1; }
 int sf_comm_size(const sf_comm* c) { return c ? c->nranks : 0; }
 

@@ -75,18 +75,51 @@ class HipEngine:
                     print(f"[sparseframe-hip] rank {rank}: C-side RCCL communicator unavailable ({e}); falling back to torch.distributed",
                           file=sys.stderr)
                     ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                if int(flag.item()) == 0 and self.comm is not None:
-                    self.comm.close()
+                def agreed(ok):
+                    flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{device}")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                    return int(flag.item()) != 0
+
+                def give_up(what, e):
+                    import sys
+                    print(f"[sparseframe-hip] rank {rank}: {what} failed ({e}); falling back to torch.distributed", file=sys.stderr)
+                    return 0
+
+                plan = None
+                if not agreed(ok):
+                    ok = 0
+                if ok:
+                    # proportionally mapped plan (a top supernode lives on the ranks below it), groups and their collectives
+                    # handled by the C library
+                    try:
+                        plan = cls(sym, device=device, owner=owner, rank=rank, nranks=world)
+                    except Exception as e:      # noqa: BLE001
+                        ok = give_up("the mapped plan", e)
+                    if not agreed(ok):          # (before the collective below: a rank without a plan must not leave the others in it)
+                        ok = 0
+                if ok:
+                    try:
+                        plan.prepare_comm(self.comm)        # sub-communicators + one checked sum per communicator, now
+                        if os.environ.get("SF_TEST_FAIL_COMM_CHECK") == "1":     # tests: the fall-back below
+                            raise RuntimeError("SF_TEST_FAIL_COMM_CHECK")
+                    except Exception as e:      # noqa: BLE001
+                        ok = give_up("the communicator check", e)
+                    if not agreed(ok):
+                        ok = 0
+                if not ok:
+                    # (communicator first: RCCL still refers to the stream of its last collective, which is the plan's)
+                    if self.comm is not None:
+                        self.comm.close()
                     self.comm = None
-        if self.lu and world == 1 and self.comm is None:
+                    if plan is not None:
+                        plan.close()
+                else:
+                    self.plan = plan
+                    self.comm_kind = "rccl-c"
+        if self.comm is not None:
+            pass
+        elif self.lu and world == 1:
             self.plan = LUPlan(sym, device=device)
-        elif self.comm is not None:
-            # proportionally mapped plan (a top supernode lives on the ranks below it), groups and their collectives handled by
-            # the C library
-            self.plan = cls(sym, device=device, owner=owner, rank=rank, nranks=world)
-            self.comm_kind = "rccl-c"
         else:
             self.plan = cls(sym, device=device, phase=phase, load_top=load_top,
                             rank=rank if self.distributed else 0, nranks=world if self.distributed else 1)
