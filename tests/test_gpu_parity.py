@@ -342,6 +342,33 @@ def test_rccl_c_path_glue_one_rank():
     assert p.returncode == 0 and "RCCL_C_GLUE_OK" in p.stdout, p.stdout[-3000:]
 
 
+@pytest.mark.parametrize("comm,method", [("rccl-c", "cholesky"), ("rccl-c", "lu"), ("torch", "cholesky")])
+def test_bench_multi_gpu_code_path_on_one_rank(comm, method):
+    """bench.py's N > 1 branch (nccl group, sharded factorization, barriers and the max-over-ranks timing, the distributed
+    solve and its residual) forced onto ONE rank (SF_FORCE_DISTRIBUTED=1): the line must come out, name the collectives that
+    ran, and carry a residual at rounding level.  `torch` = the fall-back with torch.distributed's all-reduce."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SF_FORCE_DISTRIBUTED="1", SF_BENCH_COMM=comm)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "24",
+           "--method", method, "--cpu-grid", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+    sh = line["config"]["sharding"]
+    assert sh is not None and sh["mode"] == "distributed" and sh["collectives"] == comm, sh
+    if comm == "rccl-c":
+        assert line["config"]["residual_distributed_solve"] <= 1e-13, line["config"]
+
+
 @pytest.mark.parametrize("case", small_cases(), ids=lambda c: c[0])
 def test_device_solve_matches_oracle(oracle, case):
     """sf_chol_plan_solve (level-scheduled, factor resident) vs the reference's host loops (oracle restatement)"""
