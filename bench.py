@@ -304,6 +304,10 @@ def main():
                                     "supernode lives on the ranks whose subtrees lie below it): large GEMMs split over that group, every "
                                     "top panel all-reduced once inside it (RCCL sub-communicators, issued by the C library on the "
                                     "plan's stream) block by block, 64-column chains replicated inside the group")
+                                   if (sharded.mode == "distributed" and getattr(sharded.engine, "comm_kind", "") == "rccl-c") else
+                                   ("elimination-tree subtrees sharded over the GPUs; top supernodes on every rank, their large GEMMs "
+                                    "split over the ranks and every 512-column block all-reduced once by torch.distributed (the fall-back "
+                                    "of the C-side RCCL path), 64-column chains replicated")
                                    if sharded.mode == "distributed" else
                                    ("elimination-tree subtrees sharded over the GPUs, one RCCL all-reduce of the top panels, "
                                     "top supernodes replicated")) if sharded is not None else
