@@ -726,6 +726,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // rank once factored: their pieces are dealt out over the ranks so that every PCIe link carries a share.
     {
         if (const char* env = getenv("SF_DL_WORKERS")) p->dl_workers = std::max(1, std::min(DL_WORKERS_MAX, atoi(env)));
+        if (const char* env = getenv("SF_DL_HOST_WAIT")) p->dl_host_wait = atoi(env) != 0;
         if (const char* env = getenv("SF_DL_SLOT_MB")) p->dl_slot = (int64_t)std::max(1, atoi(env)) << 17;
         const int64_t DL_SLOT = p->dl_slot;
         bool dl_2d = true;
@@ -914,7 +915,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         p->dl_events.assign(p->dl_ev_ready.size(), nullptr);
         {
             bool ok = true;
-            for (hipEvent_t& e : p->dl_events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            for (hipEvent_t& e : p->dl_events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;    // the copy workers sleep on them
             if (!ok) { rc = SF_ERR_HIP; break; }
         }
         if ((rc = upload(&p->d_Lp, Lp64, &p->bytes_device))) break;
@@ -1710,7 +1711,25 @@ static void dl_worker(sf_chol_plan* p, int w) {
         }
         if (!p->dl_trace.empty()) p->dl_trace[3 * k] = dl_now() - p->dl_t0;
         double* hslot = p->h_ring + ((int64_t)w * 2 + slot) * DL_SLOT;
-        bool ok = hipStreamWaitEvent(ws, p->dl_events[pc.ev], 0) == hipSuccess;
+        // The piece's event is waited for on the HOST, by this thread, and the copy is enqueued with nothing in front of it.  A
+        // device-side wait (hipStreamWaitEvent, SF_DL_HOST_WAIT=0) sits in the hardware queue the runtime has put this stream on
+        // and holds up whatever else shares that queue -- another worker's copy of a piece that has long been ready, or a stream
+        // of the caller's (the runtime multiplexes all streams of one priority over 4 hardware queues; plan_create has the story).
+        // While the event is still in the future, the previous piece is copied out of the ring first.
+        bool ok = true;
+        if (p->dl_host_wait) {
+            if (prev < np) {
+                const hipError_t q = hipEventQuery(p->dl_events[pc.ev]);
+                if (q != hipSuccess) {
+                    (void)hipGetLastError();            // hipErrorNotReady is not an error
+                    ok = drain(prev, prev_slot);
+                    prev = np;
+                }
+            }
+            ok = ok && hipEventSynchronize(p->dl_events[pc.ev]) == hipSuccess;
+        } else {
+            ok = hipStreamWaitEvent(ws, p->dl_events[pc.ev], 0) == hipSuccess;
+        }
         const double* src = p->d_Lsx + pc.dev_off;
         if (pc.s0 >= 0) {
             // LU, direct form: the L run as it is; the U^T run as it is (whole supernodes) or rows [nscol, nsrow) of its columns

@@ -120,6 +120,7 @@ struct sf_chol_plan {
     // LU direct download: before a piece's event is recorded, the upper triangle (with the diagonal) of its columns' part of the
     // supernode's diagonal block is filled into the L panel from the U^T panel (k_lu_fill_u11), so that the L panel holds the
     // reference's packed L11 \ U11 and the download needs no gather kernel
+    bool dl_host_wait = true;                   // copy workers wait for a piece's event on the host (see dl_worker)
     bool dl_lu_direct = false;
     void* d_fill = nullptr;                     // sf::FillTile[], grouped by download event
     std::vector<int64_t> fill_first;            // tiles of event k: [fill_first[k], fill_first[k + 1])
