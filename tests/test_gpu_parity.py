@@ -101,6 +101,38 @@ def test_struct_entry_points_end_to_end(oracle, tmp_path):
     common.close()
 
 
+@pytest.mark.parametrize("knobs", [
+    {"SF_DL_HOST_WAIT": "0"}, {"SF_DL_WORKERS": "1"}, {"SF_DL_WORKERS": "8", "SF_DL_SLOT_MB": "1"}, {"SF_DL_2D": "0"},
+    {"SF_STREAM_PRIORITY": "0"}, {"SF_DL_PIN": "1"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_struct_copy_back_knobs(oracle, monkeypatch, knobs):
+    """every alternative of the overlapped copy-back (device-side event waits, 1 / 8 workers, 1 MiB slots so that this matrix has
+    many pieces and 2-D pieces, 1-D copies only, ordinary streams, NUMA-confined workers): SparseFrame_factorize must leave the
+    same Lsx -- every stored value, including the zero-filled rows above the block columns -- twice in a row"""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    N = 26
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    perm = sf.grid_nd_perm(N, N, N)
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, 4 << 30)
+    assert np.diff(sym.Super).max() > 512                # a panel of two outer blocks: 2-D pieces exist
+    ref, info, _ = oracle.chol_factorize(sym)
+    mask = oracle.lower_mask(sym)
+    common = sf.CommonInfo(dev_slot_size=4 << 30)
+    for scale in (1.0, 4.0):
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx * scale)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        C.memset(mi.c.Lsx, 0xff, 8 * sym.xsize)
+        mi.factorize(common)
+        got = mi.array("Lsx", sym.xsize).copy()
+        assert not np.isnan(got[mask]).any()
+        assert rel_err(got, ref * np.sqrt(scale), mask) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    common.close()
+
+
 def test_not_positive_definite_is_reported():
     n, Cp, Ci, Cx = gen.laplacian_lower(6, 6)
     Cx = Cx.copy()
