@@ -71,7 +71,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_fill};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_fill, p->d_solveT, p->d_solveT_list};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -590,6 +590,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // ---------------- device solve schedule (unsharded plans) ----------------
     // per (level, SV_B-column step): a forward launch [diagonal tasks, SV_ROWS-row tiles] and a backward launch [tiles, diagonal tasks]
     std::vector<sf::SolveTask> solve;
+    std::vector<int64_t> solveT_list;      // backward diagonal tasks that read a row-major copy of their block (indices into `solve`)
+    int64_t solveT_size = 0;
     int32_t n_solve_sync = 0;
     // A mapped plan (create_mapped: one rank's subtrees + the top supernodes above them) gets a schedule too, over the panels it
     // stores -- the distributed solve (sf_chol_plan_solve_distributed, sf_multi.hip):
@@ -618,6 +620,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         const int tile = sf::SV_ROWS;
         // default: fused (35.3 ms at 128^3); SF_SOLVE_BWD_FUSED=0: two launches per backward step (38.2 ms)
+        const bool solve_diagT = !(getenv("SF_SOLVE_DIAGT") && atoi(getenv("SF_SOLVE_DIAGT")) == 0);
         const bool bwd_fused = !(getenv("SF_SOLVE_BWD_FUSED") && atoi(getenv("SF_SOLVE_BWD_FUSED")) == 0);
         p->solve_bwd_fused = bwd_fused;
         for (int l = 0; l < nlevels; ++l) {
@@ -684,7 +687,19 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 for (sf::SolveTask t : rows) { t.flag += 1; solve.push_back(t); }
                 // backward: one launch, the diagonal task waits for a tile counter (SF_SOLVE_BWD_FUSED=0: the row tiles and
                 // the diagonal tasks as TWO launches -- measured slower)
-                for (sf::SolveTask t : dg) { t.flag += 1; if (!bwd_fused) t.expect = 0; solve.push_back(t); }
+                for (sf::SolveTask t : dg) {
+                    t.flag += 1;
+                    if (!bwd_fused) t.expect = 0;
+                    // the steps of the top levels (few supernodes per level: their chain of diagonal tasks IS the backward
+                    // sweep's critical path) read their diagonal block from a row-major copy: coalesced instead of one cache line
+                    // per lane (128^3: backward sweep 19.8 -> see DESIGN 8; SF_SOLVE_DIAGT=0: off)
+                    if (solve_diagT && wide.size() <= 16 && t.b > sf::NB) {
+                        t.tdiag = 1 + solveT_size;
+                        solveT_size += (int64_t)t.b * t.b;
+                        solveT_list.push_back((int64_t)solve.size());
+                    }
+                    solve.push_back(t);
+                }
                 st.count = (int)(dg.size() + rows.size());
                 st.nrows_tasks = (int)rows.size();
                 st.big = 0;
@@ -956,6 +971,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         if (!solve.empty()) {
             if ((rc = upload(&p->d_solve, solve, &p->bytes_device))) break;
+            if (!solveT_list.empty()) {
+                if ((rc = upload(&p->d_solveT_list, solveT_list, &p->bytes_device))) break;
+                if (hipMalloc((void**)&p->d_solveT, (size_t)solveT_size * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+                p->bytes_device += (size_t)solveT_size * sizeof(double);
+                p->n_solveT = (int64_t)solveT_list.size();
+            }
             // sync words of the solve: [0] status, then the flags / counters, then two launch tickets per step
             const size_t sb = (size_t)(1 + p->n_solve_sync + 3 * p->solve_steps.size()) * sizeof(int);
             if (hipMalloc((void**)&p->d_solve_sync, sb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
@@ -2034,6 +2055,8 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
                              (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, sync, tickets + 3 * k,
                              p->d_solve_sync, st);
     }
+    // (row-major copies of the top steps' diagonal blocks, from the factor as it is now: 117 MB at 128^3, ~0.1 ms)
+    sf::launch_solve_transpose_diag(p->d_solve, p->d_solveT_list, p->n_solveT, bwd_base, p->d_solveT, st);
     for (size_t k = nst; k-- > 0;) {
         const auto& s = p->solve_steps[k];
         if (s.small) {
@@ -2041,11 +2064,12 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
             continue;
         }
         if (p->solve_bwd_fused) {
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st,
+                                 p->d_solveT);
         } else {
             sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.nrows_tasks, 0, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
             sf::launch_solve_bwd(p->d_solve + s.bwd_first + s.nrows_tasks, s.count - s.nrows_tasks, s.big, bwd_base, p->d_Lsi, p->d_x, sync,
-                                 tickets + 3 * k + 2, p->d_solve_sync, st);
+                                 tickets + 3 * k + 2, p->d_solve_sync, st, p->d_solveT);
         }
     }
     HIP_TRY(hipEventRecord(e1, st));

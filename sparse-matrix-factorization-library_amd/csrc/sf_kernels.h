@@ -155,6 +155,8 @@ struct SolveTask {
     int32_t first_col;      // Super[s]
     int32_t flag;           // index into the solve's sync words: forward = "x_blk is solved" flag, backward = tile counter
     int32_t expect;         // backward diagonal task: number of row tiles to wait for
+    int64_t tdiag;          // backward diagonal task: 1 + offset (doubles) of the step's diagonal block stored ROW by row (b x b) in the
+                            // solve's scratch, 0: none -- the task then reads the block's columns out of the panel
 };
 // forward launch: tasks = the step's diagonal tasks, then its row tiles; backward launch: the row tiles, then the diagonal
 // tasks.  sync: one word per (panel, step) and direction, zero at the start of the solve; ticket: zero, private to the launch
@@ -168,7 +170,9 @@ void launch_solve_small_bwd(const SolveTask* t, int nt, const double* Lsx, const
 void launch_solve_fwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int unit, const int32_t* pivpos,
                       int* sync, int* ticket, int* info, hipStream_t st);
 void launch_solve_bwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
-                      hipStream_t st);
+                      hipStream_t st, const double* Tbase = nullptr);
+// row-major copies of the diagonal blocks of the backward diagonal tasks list[0 .. ntasks) (indices into `tasks`) into T
+void launch_solve_transpose_diag(const SolveTask* tasks, const int64_t* list, int64_t ntasks, const double* Lsx, double* T, hipStream_t st);
 
 void launch_noop(hipStream_t st);
 

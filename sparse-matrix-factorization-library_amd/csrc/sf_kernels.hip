@@ -524,7 +524,8 @@ k_solve_fwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
 template <bool BIG>
 __global__ void __launch_bounds__(256, BIG ? 1 : 2)
 k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx, const int32_t* __restrict__ Lsi,
-            double* __restrict__ x, int* __restrict__ sync, int* __restrict__ ticket, int* __restrict__ info) {
+            double* __restrict__ x, int* __restrict__ sync, int* __restrict__ ticket, int* __restrict__ info,
+            const double* __restrict__ Tbase) {
     __shared__ int s_ticket;
     __shared__ double xs[SV_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -575,10 +576,14 @@ k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
     double bcol[NB];    // bcol[c] = D(c, lane): column `lane` of the sub-block's triangle, rows c >= lane (one contiguous run per
                         // lane: 64 cache lines per load instruction, ~7 us per block -- measured cheaper than coalesced row loads
                         // plus an in-wave transpose through LDS, which made the backward sweep 23 -> 36 ms)
+    // (steps of the top levels come with a ROW-major copy of their diagonal block, t.tdiag, made at the start of the solve:
+    // D(c, lane) is then one contiguous run across the lanes, i.e. coalesced, for bcol and for blk below)
+    const double* __restrict__ Td = (Tbase && t.tdiag) ? Tbase + (t.tdiag - 1) : nullptr;
     if (bw > 0) {
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
-            const double v = P[(t.diag + o + min(c, bw - 1)) + (int64_t)(t.diag + o + min(lane, bw - 1)) * ld];
+            const double v = Td ? Td[(int64_t)(o + min(c, bw - 1)) * b + (o + min(lane, bw - 1))]
+                                : P[(t.diag + o + min(c, bw - 1)) + (int64_t)(t.diag + o + min(lane, bw - 1)) * ld];
             bcol[c] = (lane < bw && c < bw && c >= lane) ? v : ((c == lane) ? 1.0 : 0.0);
         }
     } else {
@@ -609,7 +614,9 @@ k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
         double blk[BIG ? NB : 1];                       // L(rows of sub-block tt, this lane's column): one contiguous run
         if (BIG && above) {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) blk[k] = P[(t.diag + NB * tt + min(k, bt - 1)) + (int64_t)(t.diag + o + min(lane, bw - 1)) * ld];
+            for (int k = 0; k < NB; ++k)
+                blk[k] = Td ? Td[(int64_t)(NB * tt + min(k, bt - 1)) * b + (o + min(lane, bw - 1))]
+                            : P[(t.diag + NB * tt + min(k, bt - 1)) + (int64_t)(t.diag + o + min(lane, bw - 1)) * ld];
         }
         if (wave == tt) {
 #pragma unroll
@@ -751,10 +758,38 @@ void launch_solve_fwd(const SolveTask* t, int nt, int big, const double* Lsx, co
     else hipLaunchKernelGGL(k_solve_fwd<false>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, unit, pivpos, sync, ticket, info);
 }
 void launch_solve_bwd(const SolveTask* t, int nt, int big, const double* Lsx, const int32_t* Lsi, double* x, int* sync, int* ticket, int* info,
-                      hipStream_t st) {
+                      hipStream_t st, const double* Tbase) {
     if (nt <= 0) return;
-    if (big) hipLaunchKernelGGL(k_solve_bwd<true>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info);
-    else hipLaunchKernelGGL(k_solve_bwd<false>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info);
+    if (big) hipLaunchKernelGGL(k_solve_bwd<true>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info, Tbase);
+    else hipLaunchKernelGGL(k_solve_bwd<false>, dim3(nt), dim3(256), 0, st, t, Lsx, Lsi, x, sync, ticket, info, Tbase);
+}
+
+// T(r, c) = D(r, c), row-major b x b, for the lower triangle's 64 x 64 tiles of a step's diagonal block (one workgroup per tile,
+// transposed through LDS: reads run down the panel's columns, writes along the copy's rows)
+__global__ void __launch_bounds__(256)
+k_solve_transpose_diag(const SolveTask* __restrict__ tasks, const int64_t* __restrict__ list, const double* __restrict__ Lsx,
+                       double* __restrict__ T) {
+    __shared__ double tile[64][65];
+    const SolveTask t = tasks[list[blockIdx.x >> 4]];
+    const int ti = (blockIdx.x & 15) >> 2, tj = blockIdx.x & 3, b = t.b;
+    if (tj > ti || 64 * ti >= b || 64 * tj >= b || !t.tdiag) return;
+    const double* __restrict__ P = Lsx + t.panel;
+    double* __restrict__ Td = T + (t.tdiag - 1);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int r = 64 * ti + tx, c = 64 * tj + cc;
+        if (r < b && c < b) tile[cc][tx] = P[(t.diag + r) + (int64_t)(t.diag + c) * t.ld];
+    }
+    __syncthreads();
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int r = 64 * ti + rr, c = 64 * tj + tx;
+        if (r < b && c < b) Td[(int64_t)r * b + c] = tile[tx][rr];
+    }
+}
+
+void launch_solve_transpose_diag(const SolveTask* tasks, const int64_t* list, int64_t ntasks, const double* Lsx, double* T, hipStream_t st) {
+    if (ntasks <= 0) return;
+    hipLaunchKernelGGL(k_solve_transpose_diag, dim3((unsigned)(ntasks * 16)), dim3(256), 0, st, tasks, list, Lsx, T);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -418,15 +418,17 @@ int sf_chol_plan_solve_distributed(sf_chol_plan* p, sf_comm* comm, const sf_floa
                                   tickets + 3 * k, p->d_solve_sync, st);
     }
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    sf::launch_solve_transpose_diag(p->d_solve, p->d_solveT_list, p->n_solveT, bwd_base, p->d_solveT, st);      // see sf_chol_plan_solve
     for (size_t k = nst; k-- > 0;) {
         const auto& s = p->solve_steps[k];
         if (s.small) sf::launch_solve_small_bwd(p->d_solve + s.bwd_first, s.ndiag, bwd_base, p->d_Lsi, p->d_x, st);
         else if (p->solve_bwd_fused)
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
+            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st,
+                                 p->d_solveT);
         else {
             sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.nrows_tasks, 0, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
             sf::launch_solve_bwd(p->d_solve + s.bwd_first + s.nrows_tasks, s.count - s.nrows_tasks, s.big, bwd_base, p->d_Lsi, p->d_x, sync,
-                                 tickets + 3 * k + 2, p->d_solve_sync, st);
+                                 tickets + 3 * k + 2, p->d_solve_sync, st, p->d_solveT);
         }
     }
     HIP_TRY(hipGetLastError());

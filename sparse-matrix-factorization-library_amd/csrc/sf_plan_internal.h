@@ -168,6 +168,10 @@ struct sf_chol_plan {
     int8_t* d_loadmask = nullptr;
     // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
     sf::SolveTask* d_solve = nullptr;
+    // backward sweep: row-major copies of the diagonal blocks of the top levels' steps (made at the start of every solve)
+    double* d_solveT = nullptr;
+    int64_t* d_solveT_list = nullptr;
+    int64_t n_solveT = 0;
     double* d_x = nullptr;
     double* d_resid = nullptr;  // sf_chol_plan_validate: r | column sums | b | 4 norms
     // the forward launch of a step has fwd_count tasks, the backward one `count` (equal unless the plan is one rank's part of a
