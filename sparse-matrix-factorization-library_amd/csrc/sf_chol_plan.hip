@@ -621,8 +621,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         const int tile = sf::SV_ROWS;
         // default: fused (35.3 ms at 128^3); SF_SOLVE_BWD_FUSED=0: two launches per backward step (38.2 ms)
         const bool solve_diagT = !(getenv("SF_SOLVE_DIAGT") && atoi(getenv("SF_SOLVE_DIAGT")) == 0);
+        const bool bwd_ahead_env = !(getenv("SF_SOLVE_BWD_AHEAD") && atoi(getenv("SF_SOLVE_BWD_AHEAD")) == 0);
         const bool bwd_fused = !(getenv("SF_SOLVE_BWD_FUSED") && atoi(getenv("SF_SOLVE_BWD_FUSED")) == 0);
         p->solve_bwd_fused = bwd_fused;
+        const bool bwd_ahead = bwd_ahead_env && bwd_fused;
+        const bool fwd_ahead = !(getenv("SF_SOLVE_FWD_AHEAD") && atoi(getenv("SF_SOLVE_FWD_AHEAD")) == 0);
         for (int l = 0; l < nlevels; ++l) {
             sf_long maxcol = 0;
             for (sf_long s : by_level[l]) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
@@ -650,9 +653,20 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             }
             maxcol = 0;
             for (sf_long s : wide) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
+            // Backward look-ahead: the sum a diagonal task waits for, S_J = sum over the row blocks I > J of L_IJ^T x_I, only
+            // needs x_{J+1} -- solved one launch earlier -- for the tiles whose rows lie in block J + 1 ("near").  All other tiles of
+            // step J ("far": rows two blocks further down, or below the panel) read values that were final a launch earlier, so
+            // they ride in the launch of step J + 1, behind its diagonal task, and the diagonal task of step J waits for its few
+            // near tiles only.  (Forward sweep: unchanged.  SF_SOLVE_BWD_AHEAD=0 or the two-launch form: every tile is near.)
+            // The forward sweep looks ahead the same way: the tiles of step J whose rows lie two blocks further down (or below the
+            // panel) are not needed by the next diagonal task, so they ride in the launch of step J + 1 -- there their flag (step J's,
+            // set one launch earlier, never reset within a solve) is already up and they run at once, next to that launch's
+            // diagonal task, instead of holding a CU slot while they spin on it.  (SF_SOLVE_FWD_AHEAD=0: off.)
+            std::vector<sf::SolveTask> pending_far;        // far tiles of the step built in the previous iteration
+            std::vector<sf::SolveTask> pending_far_fwd;
             for (int diag = 0; diag < maxcol; diag += sf::SV_B) {
                 sf_chol_plan::SolveStep st{};
-                std::vector<sf::SolveTask> dg, rows, rows_fwd;
+                std::vector<sf::SolveTask> dg, rows, rows_fwd, far_next, far_next_fwd;
                 for (sf_long s : wide) {
                     const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
                     if (diag >= nscol) continue;
@@ -664,12 +678,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     const int cut = sh ? std::max(nscol, diag + b) : nsrow;
                     const int g = sh ? __builtin_popcount(gmask[s]) : 1, gi = sh ? group_idx(gmask[s]) : 0;
                     int below = 0;
+                    // (a supernode with no later block in this level has nothing to look ahead to: all its tiles are near)
+                    const int near_end = (bwd_ahead && nscol > diag + b) ? std::min(nscol, diag + b + sf::SV_B) : nsrow;
+                    const int near_end_fwd = (fwd_ahead && nscol > diag + b) ? std::min(nscol, diag + b + sf::SV_B) : nsrow;
                     for (int r0 = diag + b, r1 = cut; r0 < nsrow; r0 = r1, r1 = nsrow) {
                         for (int r = r0; r < r1; r += tile) {
                             const sf::SolveTask t{XP[s], Lsip[s], nsrow, diag, b, r, std::min(tile, r1 - r), (int32_t)Super[s], n_solve_sync, 0};
-                            rows.push_back(t);
-                            ++ntiles;
-                            if (!sh || r < nscol || (below++ % g) == gi) rows_fwd.push_back(t);
+                            if (r < near_end) { rows.push_back(t); ++ntiles; }
+                            else { far_next.push_back(t); far_next.back().flag = -1; }       // counts for nobody: a scratch word, set below
+                            if (!sh || r < nscol || (below++ % g) == gi) ((fwd_ahead && r >= near_end_fwd) ? far_next_fwd : rows_fwd).push_back(t);
                         }
                         if (r1 >= nsrow) break;
                     }
@@ -680,7 +697,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 st.fwd_first = (int64_t)solve.size();
                 solve.insert(solve.end(), dg.begin(), dg.end());
                 solve.insert(solve.end(), rows_fwd.begin(), rows_fwd.end());
-                st.fwd_count = (int)(dg.size() + rows_fwd.size());
+                solve.insert(solve.end(), pending_far_fwd.begin(), pending_far_fwd.end());
+                st.fwd_count = (int)(dg.size() + rows_fwd.size() + pending_far_fwd.size());
+                pending_far_fwd.swap(far_next_fwd);
                 st.red_first = red_first; st.red_count = red_count;
                 red_count = 0;                      // the sums belong to the level's first step
                 st.bwd_first = (int64_t)solve.size();
@@ -700,7 +719,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     }
                     solve.push_back(t);
                 }
-                st.count = (int)(dg.size() + rows.size());
+                // the far tiles of the step before this one (lower column block): their rows' x is final when this launch starts
+                solve.insert(solve.end(), pending_far.begin(), pending_far.end());
+                st.count = (int)(dg.size() + rows.size() + pending_far.size());
+                pending_far.swap(far_next);
                 st.nrows_tasks = (int)rows.size();
                 st.big = 0;
                 for (const sf::SolveTask& t : dg) st.big |= t.b > sf::NB;
@@ -710,7 +732,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             }
         }
     }
-    p->n_solve_sync = n_solve_sync;
+    for (sf::SolveTask& t : solve)
+        if (t.flag < 0) t.flag = n_solve_sync;        // the scratch word the far tiles count on
+    p->n_solve_sync = n_solve_sync + 1;
 
     // K-step prefix of every GEMM launch (stream-K work distribution, see k_gemm)
     std::vector<uint32_t> ktprefix;
