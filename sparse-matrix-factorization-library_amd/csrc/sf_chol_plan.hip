@@ -1002,7 +1002,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 p->n_solveT = (int64_t)solveT_list.size();
             }
             // sync words of the solve: [0] status, then the flags / counters, then two launch tickets per step
-            const size_t sb = (size_t)(1 + p->n_solve_sync + 3 * p->solve_steps.size()) * sizeof(int);
+            const size_t sb = (size_t)(1 + p->n_solve_sync + sf_chol_plan::SOLVE_TICKETS * p->solve_steps.size()) * sizeof(int);
             if (hipMalloc((void**)&p->d_solve_sync, sb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += sb;
             if (hipMalloc((void**)&p->d_x, std::max<int64_t>(n, 1) * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
@@ -2051,6 +2051,36 @@ double sf_chol_plan_stat(const sf_chol_plan* p, const char* name) {
 
 // x <- (L L^T)^{-1} b (Cholesky, C:3036-3139) or (L U)^{-1} b (LU, L:3592-3700) with the resident factor, permuted
 // space.  LU: unit-lower forward sweep over the L panels, backward sweep over the U^T panels (U x = y <=> (U^T)^T x = y).
+}   // extern "C"
+
+void sf_solve_step_fwd(sf_chol_plan* p, size_t k, const double* base, int* sync, int* tickets, hipStream_t st) {
+    const auto& s = p->solve_steps[k];
+    const int32_t* piv = (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr;
+    const int unit = p->lu ? 1 : 0;
+    int* tk = tickets + sf_chol_plan::SOLVE_TICKETS * k;
+    if (s.small) {
+        sf::launch_solve_small_fwd(p->d_solve + s.fwd_first, s.ndiag, base, p->d_Lsi, p->d_x, unit, piv, st);
+    } else {
+        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.fwd_count, s.big, base, p->d_Lsi, p->d_x, unit, piv, sync, tk, p->d_solve_sync, st);
+    }
+}
+
+void sf_solve_step_bwd(sf_chol_plan* p, size_t k, const double* base, int* sync, int* tickets, hipStream_t st) {
+    const auto& s = p->solve_steps[k];
+    int* tk = tickets + sf_chol_plan::SOLVE_TICKETS * k;
+    if (s.small) {
+        sf::launch_solve_small_bwd(p->d_solve + s.bwd_first, s.ndiag, base, p->d_Lsi, p->d_x, st);
+    } else if (p->solve_bwd_fused) {
+        sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, base, p->d_Lsi, p->d_x, sync, tk + 1, p->d_solve_sync, st, p->d_solveT);
+    } else {
+        sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.nrows_tasks, 0, base, p->d_Lsi, p->d_x, sync, tk + 1, p->d_solve_sync, st);
+        sf::launch_solve_bwd(p->d_solve + s.bwd_first + s.nrows_tasks, s.count - s.nrows_tasks, s.big, base, p->d_Lsi, p->d_x, sync, tk + 2,
+                             p->d_solve_sync, st, p->d_solveT);
+    }
+}
+
+extern "C" {
+
 int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host) {
     if (!p || !b_host || !x_host) return SF_ERR_ARG;
     if (p->partial || (p->nsuper > 0 && !p->d_solve)) return SF_ERR_ARG;
@@ -2067,35 +2097,11 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     const size_t nst = p->solve_steps.size();
     int* sync = p->d_solve_sync + 1;
     int* tickets = sync + p->n_solve_sync;
-    HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + 3 * nst) * sizeof(int), st));
-    for (size_t k = 0; k < nst; ++k) {
-        const auto& s = p->solve_steps[k];
-        if (s.small) {
-            sf::launch_solve_small_fwd(p->d_solve + s.fwd_first, s.ndiag, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
-                                       (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, st);
-            continue;
-        }
-        sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.fwd_count, s.big, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0,
-                             (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr, sync, tickets + 3 * k,
-                             p->d_solve_sync, st);
-    }
+    HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + sf_chol_plan::SOLVE_TICKETS * nst) * sizeof(int), st));
+    for (size_t k = 0; k < nst; ++k) sf_solve_step_fwd(p, k, fwd_base, sync, tickets, st);
     // (row-major copies of the top steps' diagonal blocks, from the factor as it is now: 117 MB at 128^3, ~0.1 ms)
     sf::launch_solve_transpose_diag(p->d_solve, p->d_solveT_list, p->n_solveT, bwd_base, p->d_solveT, st);
-    for (size_t k = nst; k-- > 0;) {
-        const auto& s = p->solve_steps[k];
-        if (s.small) {
-            sf::launch_solve_small_bwd(p->d_solve + s.bwd_first, s.ndiag, bwd_base, p->d_Lsi, p->d_x, st);
-            continue;
-        }
-        if (p->solve_bwd_fused) {
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st,
-                                 p->d_solveT);
-        } else {
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.nrows_tasks, 0, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first + s.nrows_tasks, s.count - s.nrows_tasks, s.big, bwd_base, p->d_Lsi, p->d_x, sync,
-                                 tickets + 3 * k + 2, p->d_solve_sync, st, p->d_solveT);
-        }
-    }
+    for (size_t k = nst; k-- > 0;) sf_solve_step_bwd(p, k, bwd_base, sync, tickets, st);
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(x_host, p->d_x, p->n * sizeof(double), hipMemcpyDeviceToHost, st));

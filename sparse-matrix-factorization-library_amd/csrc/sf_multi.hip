@@ -403,8 +403,7 @@ int sf_chol_plan_solve_distributed(sf_chol_plan* p, sf_comm* comm, const sf_floa
     const size_t nst = p->solve_steps.size();
     int* sync = p->d_solve_sync + 1;
     int* tickets = sync + p->n_solve_sync;
-    if (p->d_solve_sync) HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + 3 * nst) * sizeof(int), st));
-    const int32_t* piv = (p->lu && p->piv_tol > 0.0) ? p->d_piv : nullptr;
+    if (p->d_solve_sync) HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + sf_chol_plan::SOLVE_TICKETS * nst) * sizeof(int), st));
     for (size_t k = 0; k < nst && !rc; ++k) {
         const auto& s = p->solve_steps[k];
         for (int q = 0; q < s.red_count && !rc; ++q) {
@@ -413,24 +412,11 @@ int sf_chol_plan_solve_distributed(sf_chol_plan* p, sf_comm* comm, const sf_floa
             rc = gc ? sf_comm_allreduce_sum(gc, (void*)(p->d_x + R.off), R.cnt, (void*)st) : SF_ERR_ARG;
         }
         if (rc) break;
-        if (s.small) sf::launch_solve_small_fwd(p->d_solve + s.fwd_first, s.ndiag, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0, piv, st);
-        else sf::launch_solve_fwd(p->d_solve + s.fwd_first, s.fwd_count, s.big, fwd_base, p->d_Lsi, p->d_x, p->lu ? 1 : 0, piv, sync,
-                                  tickets + 3 * k, p->d_solve_sync, st);
+        sf_solve_step_fwd(p, k, fwd_base, sync, tickets, st);
     }
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
     sf::launch_solve_transpose_diag(p->d_solve, p->d_solveT_list, p->n_solveT, bwd_base, p->d_solveT, st);      // see sf_chol_plan_solve
-    for (size_t k = nst; k-- > 0;) {
-        const auto& s = p->solve_steps[k];
-        if (s.small) sf::launch_solve_small_bwd(p->d_solve + s.bwd_first, s.ndiag, bwd_base, p->d_Lsi, p->d_x, st);
-        else if (p->solve_bwd_fused)
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.count, s.big, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st,
-                                 p->d_solveT);
-        else {
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first, s.nrows_tasks, 0, bwd_base, p->d_Lsi, p->d_x, sync, tickets + 3 * k + 1, p->d_solve_sync, st);
-            sf::launch_solve_bwd(p->d_solve + s.bwd_first + s.nrows_tasks, s.count - s.nrows_tasks, s.big, bwd_base, p->d_Lsi, p->d_x, sync,
-                                 tickets + 3 * k + 2, p->d_solve_sync, st, p->d_solveT);
-        }
-    }
+    for (size_t k = nst; k-- > 0;) sf_solve_step_bwd(p, k, bwd_base, sync, tickets, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(xb.data(), p->d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     int sinfo = 0;

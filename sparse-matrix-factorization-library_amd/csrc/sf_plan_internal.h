@@ -100,6 +100,10 @@ struct DlPiece {
 };
 
 struct sf_comm;      // one rank's end of a multi-GPU group (sf_multi.hip)
+struct sf_chol_plan;
+// one step of the solve sweeps (sf_chol_plan.hip; shared by sf_chol_plan_solve and sf_chol_plan_solve_distributed)
+void sf_solve_step_fwd(sf_chol_plan* p, size_t k, const double* base, int* sync, int* tickets, hipStream_t st);
+void sf_solve_step_bwd(sf_chol_plan* p, size_t k, const double* base, int* sync, int* tickets, hipStream_t st);
 
 struct sf_chol_plan {
     // ---- overlapped download schedule (built once) and the state of a running download ----
@@ -178,6 +182,7 @@ struct sf_chol_plan {
     // distributed factor: the forward tiles that update ancestors' rows are dealt out over the group, the backward ones are not);
     // big: a panel of the step is wider than 64 columns; red_first / red_count: sums over a group that precede the forward launch
     struct SolveStep { int64_t fwd_first, bwd_first; int count; int big; int nrows_tasks; int small; int ndiag; int fwd_count; int red_first, red_count; };
+    static constexpr int SOLVE_TICKETS = 3;     // ticket words per step: forward, backward, the backward sweep's second launch (two-launch form)
     struct SolveReduce { int64_t off, cnt; uint32_t mask; };        // x[off .. off + cnt) summed over the ranks of `mask`
     std::vector<SolveReduce> solve_reduces;
     std::vector<std::pair<int64_t, int64_t>> solve_own;           // column ranges whose solution this rank reports (distributed solve)
