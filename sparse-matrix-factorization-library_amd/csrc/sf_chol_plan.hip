@@ -626,6 +626,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         p->solve_bwd_fused = bwd_fused;
         const bool bwd_ahead = bwd_ahead_env && bwd_fused;
         const bool fwd_ahead = !(getenv("SF_SOLVE_FWD_AHEAD") && atoi(getenv("SF_SOLVE_FWD_AHEAD")) == 0);
+        int solve_far_wgs = 512;
+        if (const char* env = getenv("SF_SOLVE_FAR_WGS")) solve_far_wgs = std::max(1, atoi(env));
+        int solve_far_groups = 8;
+        if (const char* env = getenv("SF_SOLVE_FAR_GROUPS")) solve_far_groups = std::max(1, std::min(64, atoi(env)));
         for (int l = 0; l < nlevels; ++l) {
             sf_long maxcol = 0;
             for (sf_long s : by_level[l]) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
@@ -664,6 +668,22 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             // diagonal task, instead of holding a CU slot while they spin on it.  (SF_SOLVE_FWD_AHEAD=0: off.)
             std::vector<sf::SolveTask> pending_far;        // far tiles of the step built in the previous iteration
             std::vector<sf::SolveTask> pending_far_fwd;
+            // Far tiles are merged into tasks of up to 8 consecutive 64-row groups of one panel (k_solve_*: one workgroup streams
+            // through them; backward: ONE butterfly and ONE set of atomics per task instead of one per 64 rows, on the 256 words
+            // all tiles of a step add to), as long as that leaves ~512 workgroups to the launch.  SF_SOLVE_FAR_GROUPS=1: off.
+            auto group_far = [&](std::vector<sf::SolveTask>& v) {
+                const int G = std::max(1, std::min(solve_far_groups, (int)(v.size() / (size_t)solve_far_wgs)));
+                if (G <= 1 || v.empty()) return false;
+                std::vector<sf::SolveTask> out;
+                for (const sf::SolveTask& t : v) {
+                    if (!out.empty() && out.back().panel == t.panel && out.back().diag == t.diag && out.back().flag == t.flag &&
+                        out.back().row0 + out.back().nrows == t.row0 && out.back().nrows % tile == 0 && out.back().nrows + t.nrows <= G * tile)
+                        out.back().nrows += t.nrows;
+                    else out.push_back(t);
+                }
+                v.swap(out);
+                return true;
+            };
             for (int diag = 0; diag < maxcol; diag += sf::SV_B) {
                 sf_chol_plan::SolveStep st{};
                 std::vector<sf::SolveTask> dg, rows, rows_fwd, far_next, far_next_fwd;
@@ -697,6 +717,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 st.fwd_first = (int64_t)solve.size();
                 solve.insert(solve.end(), dg.begin(), dg.end());
                 solve.insert(solve.end(), rows_fwd.begin(), rows_fwd.end());
+                const bool grouped_fwd = group_far(pending_far_fwd);
                 solve.insert(solve.end(), pending_far_fwd.begin(), pending_far_fwd.end());
                 st.fwd_count = (int)(dg.size() + rows_fwd.size() + pending_far_fwd.size());
                 pending_far_fwd.swap(far_next_fwd);
@@ -720,12 +741,14 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     solve.push_back(t);
                 }
                 // the far tiles of the step before this one (lower column block): their rows' x is final when this launch starts
+                const bool grouped_bwd = group_far(pending_far);
                 solve.insert(solve.end(), pending_far.begin(), pending_far.end());
                 st.count = (int)(dg.size() + rows.size() + pending_far.size());
                 pending_far.swap(far_next);
                 st.nrows_tasks = (int)rows.size();
                 st.big = 0;
                 for (const sf::SolveTask& t : dg) st.big |= t.b > sf::NB;
+                if (grouped_bwd || grouped_fwd) st.big = 1;     // only that instantiation of the kernels walks through row groups
                 st.small = 0;
                 st.ndiag = (int)dg.size();
                 p->solve_steps.push_back(st);

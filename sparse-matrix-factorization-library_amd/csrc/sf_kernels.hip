@@ -499,26 +499,53 @@ k_solve_fwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
         return;
     }
     // ---- row tile: lane = row, wave = 64-column chunk; the 64 entries are in flight while the diagonal block is solved ----
-    const int r = t.row0 + min(lane, t.nrows - 1);
-    const double* Lr = Lsx + t.panel + r + (int64_t)(t.diag + o) * ld;
+    // (a "far" tile of a look-ahead step may hold several 64-row groups, t.nrows > 64: one workgroup streams through them -- one
+    // ticket, one task, one flag poll, one load of x_blk for all of them)
+    int nr = min(t.nrows, SV_ROWS);
+    int r = t.row0 + min(lane, nr - 1);
     double lr[NB];
     if (bw > 0) {
+        const double* Lr = Lsx + t.panel + r + (int64_t)(t.diag + o) * ld;
 #pragma unroll
         for (int k = 0; k < NB; ++k) lr[k] = Lr[(int64_t)min(k, bw - 1) * ld];
     }
-    const int32_t gi = Lsi[t.rows + r];
+    int32_t gi = Lsi[t.rows + r];
     if (tid == 0) sv_wait(sync + t.flag, 1, info);
     __syncthreads();
     xs[tid] = (tid < b) ? __builtin_nontemporal_load(x + t.first_col + t.diag + tid) : 0.0;
     __syncthreads();
-    double acc = 0.0;
-    if (bw > 0) {
+    {
+        double acc = 0.0;
+        if (bw > 0) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) acc += lr[k] * xs[o + k];       // columns beyond b meet xs = 0
+            for (int k = 0; k < NB; ++k) acc += lr[k] * xs[o + k];       // columns beyond b meet xs = 0
+        }
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && lane < nr) unsafeAtomicAdd(x + gi, -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]));
     }
-    part[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && lane < t.nrows) unsafeAtomicAdd(x + gi, -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]));
+    if (BIG) {          // (only this instantiation walks through further row groups; the plan makes sure of it)
+#pragma unroll 1
+        for (int g0 = SV_ROWS; g0 < t.nrows; g0 += SV_ROWS) {
+            nr = min(t.nrows - g0, SV_ROWS);
+            r = t.row0 + g0 + min(lane, nr - 1);
+            if (bw > 0) {
+                const double* Lr = Lsx + t.panel + r + (int64_t)(t.diag + o) * ld;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) lr[k] = Lr[(int64_t)min(k, bw - 1) * ld];
+            }
+            gi = Lsi[t.rows + r];
+            double acc = 0.0;
+            if (bw > 0) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) acc += lr[k] * xs[o + k];
+            }
+            __syncthreads();            // part[] of the previous group has been read
+            part[wave][lane] = acc;
+            __syncthreads();
+            if (wave == 0 && lane < nr) unsafeAtomicAdd(x + gi, -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]));
+        }
+    }
 }
 
 template <bool BIG>
@@ -541,15 +568,35 @@ k_solve_bwd(const SolveTask* __restrict__ tasks, const double* __restrict__ Lsx,
         // over the 64 lanes for every k: a transposing butterfly -- in the step with mask m a lane keeps the half of its
         // array that matches its bit m and adds the partner's other half -- leaves lane l with the sum of ONE column after
         // 63 exchanges instead of 64 full reductions.
-        const int rr = t.row0 + min(lane, t.nrows - 1);
-        const double* Lr = Lsx + t.panel + rr + (int64_t)(t.diag + o) * ld;
+        // (a "far" tile of a look-ahead step may hold several 64-row groups, t.nrows > 64: their products are summed in
+        // registers first -- the butterfly is linear -- so the group of tiles costs ONE butterfly and ONE set of atomics on the
+        // 256 words every tile of the step adds to)
         double p[NB];
         if (bw > 0) {
+            int nr = min(t.nrows, SV_ROWS);
+            int rr = t.row0 + min(lane, nr - 1);
+            {
+                const double* Lr = Lsx + t.panel + rr + (int64_t)(t.diag + o) * ld;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) p[k] = Lr[(int64_t)min(k, bw - 1) * ld];
-            const double xr = (lane < t.nrows) ? x[Lsi[t.rows + rr]] : 0.0;
+                for (int k = 0; k < NB; ++k) p[k] = Lr[(int64_t)min(k, bw - 1) * ld];
+                const double xr = (lane < nr) ? x[Lsi[t.rows + rr]] : 0.0;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) p[k] *= xr;
+                for (int k = 0; k < NB; ++k) p[k] *= xr;
+            }
+            if (BIG) {
+#pragma unroll 1
+                for (int g0 = SV_ROWS; g0 < t.nrows; g0 += SV_ROWS) {
+                    nr = min(t.nrows - g0, SV_ROWS);
+                    rr = t.row0 + g0 + min(lane, nr - 1);
+                    const double* Lr = Lsx + t.panel + rr + (int64_t)(t.diag + o) * ld;
+                    double q[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) q[k] = Lr[(int64_t)min(k, bw - 1) * ld];
+                    const double xr = (lane < nr) ? x[Lsi[t.rows + rr]] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) p[k] += q[k] * xr;
+                }
+            }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 const bool up = (lane & m) != 0;
