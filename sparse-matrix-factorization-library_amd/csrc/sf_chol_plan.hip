@@ -626,6 +626,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         p->solve_bwd_fused = bwd_fused;
         const bool bwd_ahead = bwd_ahead_env && bwd_fused;
         const bool fwd_ahead = !(getenv("SF_SOLVE_FWD_AHEAD") && atoi(getenv("SF_SOLVE_FWD_AHEAD")) == 0);
+        const bool fwd_far_first = !(getenv("SF_SOLVE_FWD_FAR_FIRST") && atoi(getenv("SF_SOLVE_FWD_FAR_FIRST")) == 0);
         int solve_far_wgs = 512;
         if (const char* env = getenv("SF_SOLVE_FAR_WGS")) solve_far_wgs = std::max(1, atoi(env));
         int solve_far_groups = 8;
@@ -716,9 +717,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 }
                 st.fwd_first = (int64_t)solve.size();
                 solve.insert(solve.end(), dg.begin(), dg.end());
-                solve.insert(solve.end(), rows_fwd.begin(), rows_fwd.end());
+                // order of the forward list = order in which workgroups take their tasks: diagonal tasks, then the far tiles of the
+                // step before (nothing to wait for: they start at once), the near tiles last -- taken first they would sit in
+                // the CU slots spinning on the diagonal tasks' flags and keep the far tiles out until those are up
                 const bool grouped_fwd = group_far(pending_far_fwd);
-                solve.insert(solve.end(), pending_far_fwd.begin(), pending_far_fwd.end());
+                if (fwd_far_first) solve.insert(solve.end(), pending_far_fwd.begin(), pending_far_fwd.end());
+                solve.insert(solve.end(), rows_fwd.begin(), rows_fwd.end());
+                if (!fwd_far_first) solve.insert(solve.end(), pending_far_fwd.begin(), pending_far_fwd.end());
                 st.fwd_count = (int)(dg.size() + rows_fwd.size() + pending_far_fwd.size());
                 pending_far_fwd.swap(far_next_fwd);
                 st.red_first = red_first; st.red_count = red_count;
