@@ -414,6 +414,39 @@ def test_device_solve_matches_oracle(oracle, case):
     plan.close()
 
 
+@pytest.mark.parametrize("knobs", [
+    {"SF_SOLVE_FAR_WGS": "1", "SF_SOLVE_FAR_GROUPS": "64"},      # far tiles merged into multi-group tasks even on this small matrix
+    {"SF_SOLVE_FAR_WGS": "1", "SF_SOLVE_FAR_GROUPS": "3", "SF_SOLVE_FWD_FAR_FIRST": "0"},
+    {"SF_SOLVE_BWD_AHEAD": "0", "SF_SOLVE_FWD_AHEAD": "0", "SF_SOLVE_DIAGT": "0"},     # the sweeps without look-ahead
+    {"SF_SOLVE_BWD_FUSED": "0"}], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("method", ["cholesky", "lu"])
+def test_device_solve_schedules(oracle, monkeypatch, knobs, method):
+    """the solve's schedule variants (look-ahead of the far row tiles, multi-group far tasks, list order, row-major diagonal
+    copies, two-launch backward steps) against the reference's host loops (oracle restatement); the matrix has supernodes of
+    several 256-column steps, so every variant has something to do"""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    N = 34
+    if method == "lu":
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=5)
+        sym = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(N, N, N), 4 << 30, "lu", False)
+        plan = sf.LUPlan(sym)
+        plan.set_values(sym.Lx, sym.Ux)
+    else:
+        n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+        sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 4 << 30)
+        plan = sf.CholPlan(sym)
+        plan.set_values(sym.Lx)
+    assert np.diff(sym.Super).max() > 1024
+    plan.factorize()
+    Lsx = plan.get_factor()
+    b = 1 + np.arange(n) / n
+    x = plan.solve(b)
+    want = (oracle.lu_solve if method == "lu" else oracle.chol_solve)(sym, Lsx, b)
+    assert np.allclose(x, want, rtol=1e-11, atol=1e-12 * np.abs(want).max())
+    plan.close()
+
+
 def test_device_solve_residual_48cubed(oracle):
     N = 48
     n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
