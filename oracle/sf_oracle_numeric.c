@@ -587,6 +587,179 @@ int sfo_lu_factorize(Long n, Long nsuper, const Long* Super, const Long* SuperMa
     return c.info;
 }
 
+/* ================================================================================================
+ * LU with threshold partial pivoting RESTRICTED TO THE 64 x 64 DIAGONAL BLOCKS of a supernode, + perturbation of tiny pivots.
+ *
+ * NOT a restatement of the reference: the reference never pivots (magma_dgetrf_nopiv L:2653, devIpiv = NULL L:3344, the static
+ * pre-pivot L:589-673 is compiled out at L:784).  BASELINE config 5 asks for "partial pivoting", so the product has a rule of its
+ * own; this is that rule written down a second time, in plain scalar C with no blocking, no BLAS and explicit
+ * loops, so that the GPU tests can compare the pivot sequence, PivInv and the L / U values with something that shares no code
+ * with the kernels.  PARITY UNPINNED by construction (there is no reference behaviour to be in parity with).
+ *
+ * The rule, per supernode, column j = 0 .. nscol-1 of its front, block = the 64 columns [64 (j/64), min(64 (j/64) + 64, nscol)):
+ *   candidates  = the rows of the block (front-local indices = its columns) that have not been a pivot row yet
+ *   natural row = the row whose ORIGINAL position is j (interchanges are implicit: rows keep their place until the block is done)
+ *   m           = max |a(r, j)| over the candidates; the natural row keeps the pivot if it is a candidate, a(j, j) != 0 and
+ *                 |a(j, j)| >= tol * m; otherwise the pivot row is the candidate with |a(r, j)| = m of LOWEST original position
+ *   tol <= 0    : no search, pivot row j (the reference's behaviour)
+ *   perturbation: eps > 0 and not |pivot| >= eps (and pivot not NaN)  ->  pivot = (pivot < 0 ? -eps : eps), counted
+ *   a row chosen at column j ends at position j; what moves with it: its entries in the block's own columns and everything to
+ *   the right (rest of L11 \ U11, its row of U12).  Entries LEFT of the block (columns of earlier blocks, and the L21 rows of
+ *   descendant panels) stay where they are: the interchanges are applied LINPACK-style, block by block, in the forward sweep.
+ *   pivpos[g] = position of original row g, pivinv[position] = original row (global indices, identity outside moved rows).
+ * ================================================================================================ */
+#define SFO_PIV_NB 64
+static int sfo_lu_front_pivot(Long nscol, Long nsrow, double* A, Long slda, double tol, double eps,
+                              Long* pos /* nscol */, char* used /* nscol */, Long* nperturbed) {
+    const Long sm = nsrow - nscol;
+    int info = 0;
+#define D_(r, c) A[(c) * slda + (r)]                 /* r < nsrow: packed L11 \ U11 (r < nscol) and L21 (r >= nscol) */
+#define U12_(r, i) A[sm + (r) * slda + (i)]          /* U(r, front column i), i in [nscol, nsrow)  (stored as U12^T, L:2514-2517) */
+    for (Long r = 0; r < nscol; r++) { used[r] = 0; pos[r] = r; }
+    for (Long j = 0; j < nscol; j++) {
+        const Long k0 = (j / SFO_PIV_NB) * SFO_PIV_NB;
+        const Long k1 = (k0 + SFO_PIV_NB < nscol) ? k0 + SFO_PIV_NB : nscol;
+        Long p = j;
+        if (tol > 0.0) {
+            double m = -1.0; Long pm = -1;
+            for (Long r = k0; r < k1; r++) {
+                if (used[r]) continue;
+                const double v = fabs(D_(r, j));
+                if (v > m) { m = v; pm = r; }           /* strict: the lowest original position wins a tie */
+            }
+            const double nat = D_(j, j);
+            if (!(!used[j] && fabs(nat) >= tol * m && nat != 0.0) && pm >= 0) p = pm;
+        }
+        double piv = D_(p, j);
+        if (eps > 0.0 && !(fabs(piv) >= eps) && piv == piv) {
+            piv = (piv < 0.0) ? -eps : eps;
+            D_(p, j) = piv;
+            if (nperturbed) ++*nperturbed;
+        }
+        if (!(piv != 0.0) && !info) info = (int)(j + 1);
+        used[p] = 1; pos[p] = j;
+        /* eliminate column j from every row that is not a pivot row yet: the rest of this block, the later blocks, L21 */
+        for (Long r = k0; r < nsrow; r++) {
+            if (r < nscol && used[r]) continue;
+            const double l = D_(r, j) / piv;
+            D_(r, j) = l;
+            if (l == 0.0) continue;
+            for (Long c = j + 1; c < nscol; c++) D_(r, c) -= l * D_(p, c);
+            if (r < nscol) for (Long i = nscol; i < nsrow; i++) U12_(r, i) -= l * U12_(p, i);
+        }
+        if (j + 1 == k1 && tol > 0.0) {
+            /* the block is done: move every row to the position it was given -- the block's own columns and all to the right */
+            const Long b = k1 - k0;
+            int moved = 0;
+            for (Long r = k0; r < k1; r++) if (pos[r] != r) moved = 1;
+            if (moved) {
+                double* tmp = malloc((size_t)b * sizeof(double));
+                for (Long c = k0; c < nscol; c++) {
+                    for (Long r = k0; r < k1; r++) tmp[pos[r] - k0] = D_(r, c);
+                    for (Long r = k0; r < k1; r++) D_(r, c) = tmp[r - k0];
+                }
+                for (Long i = nscol; i < nsrow; i++) {
+                    for (Long r = k0; r < k1; r++) tmp[pos[r] - k0] = U12_(r, i);
+                    for (Long r = k0; r < k1; r++) U12_(r, i) = tmp[r - k0];
+                }
+                free(tmp);
+            }
+        }
+    }
+#undef D_
+#undef U12_
+    return info;
+}
+
+/* as sfo_lu_factorize, with the pivoting rule above.  pivpos / pivinv: n Longs each (out), nperturbed: one Long (out). */
+int sfo_lu_factorize_pivot(Long n, Long nsuper, const Long* Super, const Long* SuperMap,
+                           const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                           const Long* Lp, const Long* Li, const double* Lx,
+                           const Long* Up, const Long* Ui, const double* Ux,
+                           const Long* LeafQueue_in, Long nsleaf, Long csize, double tol, double eps,
+                           double* Lsx, Long* pivpos, Long* pivinv, Long* nperturbed) {
+    sfo_lu_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.n = n; c.nsuper = nsuper;
+    c.Super = Super; c.SuperMap = SuperMap; c.Lsip = Lsip; c.Lsi = Lsi; c.Lsxp = Lsxp;
+    c.Lp = Lp; c.Li = Li; c.Lx = Lx; c.Up = Up; c.Ui = Ui; c.Ux = Ux; c.Lsx = Lsx;
+    const size_t ns1 = (size_t)(nsuper > 0 ? nsuper : 1), n1 = (size_t)(n > 0 ? n : 1);
+    c.Head = malloc(ns1 * sizeof(Long)); c.Next = malloc(ns1 * sizeof(Long)); c.Lpos = malloc(ns1 * sizeof(Long));
+    Long* Nschild = calloc(ns1, sizeof(Long));
+    Long* Queue = malloc(ns1 * sizeof(Long));
+    c.Map = malloc(n1 * sizeof(Long)); c.RelMap = malloc(n1 * sizeof(Long));
+    c.C = malloc((size_t)(csize > 0 ? csize : 1) * sizeof(double));
+    Long* pos = malloc(n1 * sizeof(Long));
+    char* used = malloc(n1);
+    if (!c.Head || !c.Next || !c.Lpos || !Nschild || !Queue || !c.Map || !c.RelMap || !c.C || !pos || !used) return -1;
+    if (nperturbed) *nperturbed = 0;
+    for (Long i = 0; i < n; i++) { pivpos[i] = i; pivinv[i] = i; }
+    for (Long s = 0; s < nsuper; s++) { c.Head[s] = -1; c.Next[s] = -1; c.Lpos[s] = 0; }
+    for (Long s = 0; s < nsuper; s++) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        if (nscol < nsrow) Nschild[SuperMap[Lsi[Lsip[s] + nscol]]]++;
+    }
+    Long head = 0, tail = nsleaf;
+    for (Long k = 0; k < nsleaf; k++) Queue[k] = LeafQueue_in[k];
+    while (head < tail) {
+        const Long s = Queue[head++];
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s], slda = 2 * nsrow - nscol;
+        const Long* rows = Lsi + Lsip[s];
+        for (Long si = 0; si < nsrow; si++) c.Map[rows[si]] = si;
+        double* A = Lsx + Lsxp[s];
+        sfo_lu_assemble_panel(&c, s, A, nscol, nsrow, slda);
+        while (c.Head[s] >= 0) {
+            const Long d = c.Head[s];
+            c.Head[s] = c.Next[d];
+            sfo_lu_apply_descendant(&c, s, nscol, nsrow, A, d);
+        }
+        const int info = sfo_lu_front_pivot(nscol, nsrow, A, slda, tol, eps, pos, used, nperturbed);
+        if (info && !c.info) c.info = info;
+        for (Long r = 0; r < nscol; r++) { pivpos[Super[s] + r] = Super[s] + pos[r]; pivinv[Super[s] + pos[r]] = Super[s] + r; }
+        c.Lpos[s] = nscol;
+        if (nscol < nsrow) {
+            const Long sparent = SuperMap[Lsi[Lsip[s] + nscol]];
+            c.Next[s] = c.Head[sparent];
+            c.Head[sparent] = s;
+            if (--Nschild[sparent] <= 0) Queue[tail++] = sparent;
+        }
+    }
+    const int done = (head == nsuper);
+    free(c.Head); free(c.Next); free(c.Lpos); free(Nschild); free(Queue); free(c.Map); free(c.RelMap); free(c.C); free(pos); free(used);
+    if (!done) return -2;
+    return c.info;
+}
+
+/* the solve that goes with it: the interchanges of a 64-column block are applied to x right before the forward sweep reaches the
+ * block's columns (LINPACK-style), the backward sweep is the unpivoted one (U is stored in position order) */
+void sfo_lu_solve_pivot(Long nsuper, const Long* Super, const Long* Lsip, const Long* Lsi, const Long* Lsxp,
+                        const double* Lsx, const Long* pivpos, Long n, const double* b, double* x) {
+    double tmp[SFO_PIV_NB];
+    memcpy(x, b, (size_t)n * sizeof(double));
+    for (Long s = 0; s < nsuper; s++) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s], slda = 2 * nsrow - nscol;
+        for (Long k0 = 0; k0 < nscol; k0 += SFO_PIV_NB) {
+            const Long k1 = (k0 + SFO_PIV_NB < nscol) ? k0 + SFO_PIV_NB : nscol;
+            const Long g0 = Super[s] + k0;
+            for (Long r = k0; r < k1; r++) tmp[pivpos[Super[s] + r] - g0] = x[Super[s] + r];
+            for (Long r = k0; r < k1; r++) x[Super[s] + r] = tmp[r - k0];
+            for (Long sj = k0; sj < k1; sj++) {
+                const Long j = Lsi[Lsip[s] + sj];
+                for (Long si = sj + 1; si < nsrow; si++) x[Lsi[Lsip[s] + si]] -= Lsx[Lsxp[s] + sj * slda + si] * x[j];
+            }
+        }
+    }
+    for (Long s = nsuper - 1; s >= 0; s--) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s], slda = 2 * nsrow - nscol;
+        for (Long sj = nscol - 1; sj >= 0; sj--) {
+            const Long j = Lsi[Lsip[s] + sj];
+            for (Long si = sj + 1; si < nscol; si++) x[j] -= Lsx[Lsxp[s] + si * slda + sj] * x[Lsi[Lsip[s] + si]];
+            for (Long si = nscol; si < nsrow; si++) x[j] -= Lsx[Lsxp[s] + (nsrow - nscol) + sj * slda + si] * x[Lsi[Lsip[s] + si]];
+            x[j] /= Lsx[Lsxp[s] + sj * slda + sj];
+        }
+    }
+}
+
 /* L:3592-3700 */
 void sfo_lu_solve(Long nsuper, const Long* Super, const Long* Lsip, const Long* Lsi, const Long* Lsxp,
                   const double* Lsx, Long n, const double* b, double* x) {
