@@ -107,6 +107,7 @@ def secondary_case(sf, np, kind, steps=3):
         sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False)
         plan = sf.LUPlan(sym)
         plan.set_values(sym.Lx, sym.Ux)
+        plan.set_pivoting(0.1)
         wl = ("unsymmetric 3D 19-point stencil 79^3 (5% of the entries dropped one-sidedly; SURVEY 8d's one random long-range entry "
               "per row is not used: it destroys the grid separators and the fill explodes under a geometric ordering), diagonally "
               "dominant, LU fp64 with threshold partial pivoting (tol 0.1) inside the 64x64 diagonal blocks")
@@ -294,6 +295,7 @@ def main():
     elif lu:
         plan = sf.LUPlan(sym, device=local_rank)
         plan.set_values(sym.Lx, sym.Ux)
+        plan.set_pivoting(0.1)
     else:
         plan = sf.CholPlan(sym, device=local_rank)
         plan.set_values(sym.Lx)

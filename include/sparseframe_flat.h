@@ -53,6 +53,7 @@ struct gpu_info_struct;
 #define SF_ERR_ALLOC         3
 #define SF_ERR_NOT_POSDEF    4   /* non-positive pivot met in a diagonal block */
 #define SF_ERR_HIP           5
+#define SF_ERR_PEER          6   /* multi-GPU: another rank of the group reported a failure; this rank stopped with it */
 
 /* ---- host-side symbolic analysis on plain arrays (what SparseFrame_analyze forwards to).
  * The result object owns its arrays; read them through sf_symbolic_get. ---- */
@@ -221,6 +222,13 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan *plan, sf_comm *comm, sf_flo
  * for (its subtrees' columns + the columns of the shared supernodes whose group it leads), the others are left alone.  One small
  * sum per shared supernode in the forward sweep is all that travels. */
 int sf_chol_plan_solve_distributed(sf_chol_plan *plan, sf_comm *comm, const sf_float *b_host, sf_float *x_host);
+/* Failure behaviour of the two distributed drivers: everything that can fail on one rank alone is done first and the ranks agree on
+ * the outcome with one 8-byte sum BEFORE the first data collective; if any rank failed, every rank returns (its own code, or
+ * SF_ERR_PEER) with nothing enqueued on the communicator.  A failure in the middle of a run aborts this rank's communicator
+ * (ncclCommAbort; emulated ranks keep their hand-shakes going): later calls on it return SF_ERR_PEER.
+ * sf_test_inject_failure (test hook): rank `rank` fails once at `where` = 1 before the first collective of a factorization, 2 in the
+ * middle of its segments, 3 before the first collective of a solve, 4 in the middle of its forward sweep. */
+void sf_test_inject_failure(int rank, int where);
 
 /* ---- device plan for supernodal no-pivot LU (replaces L:2668-3573 + LU/Source/cuda_kernel.cu:22-176).
  * Symbolic arrays from sf_symbolic_create_lu; Lsxp is the reference's (packed (2*nsrow-nscol) x nscol) offsets.
@@ -251,7 +259,7 @@ int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *
  * row keeps the pivot while |a_jj| >= tol * max over the block's unused rows of |a_ij| -- and a pivot smaller than
  * perturb * max|a_ij| is replaced by +- that value ("perturbed_pivots" stat; refine the solution iteratively then).
  * tol in [0, 1]: 0 = no pivoting (exactly the reference's behaviour; a zero pivot is SF_ERR_NOT_POSDEF when perturb is 0 too),
- * 1 = partial pivoting.  Defaults: tol 0.1, perturb sqrt(eps) (env SF_LU_PIVOT_TOL / SF_LU_PERTURB at plan creation).  On a
+ * 1 = partial pivoting.  Defaults: tol 0, perturb 0 = the reference (env SF_LU_PIVOT_TOL at plan creation: that tol and perturb sqrt(eps); SF_LU_PERTURB).  On a
  * matrix whose natural pivots pass the threshold (e.g. diagonally dominant) the factor is bit-identical to the no-pivot one.
  * The interchanges are recorded per block and applied block by block in the forward solve (LINPACK-style: the L entries to
  * the left of a block keep their rows). */
@@ -284,11 +292,27 @@ int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_inf
                           const sf_float *Lx, const sf_float *Ux, sf_float *Lsx_out,
                           sf_long *PivOut /* LU: row positions after the in-block interchanges (n entries), or NULL */);
 
-/* The struct path's solve with the RESIDENT factor: after SparseFrame_factorize on one handler the factor is still in that handler's
- * cached plan; SparseFrame_solve_supernodal (which only receives matrix_info) asks here, by the address of the host copy.  Solves on
- * the device (b, x in the permuted numbering, n doubles each way) when the plan still holds THAT factorization and a sample of the
- * host copy (three windows of 512 values) still equals the device's; otherwise returns SF_ERR_ARG and the caller solves on the host
- * as the reference does (C:3036-3139).  SF_SOLVE=host in the environment forces the host solve.  forget: the host copy is being freed. */
+/* LU pivoting policy of the struct entry points (process-wide, takes effect at the next SparseFrame_factorize of the LU library).
+ * Default: none set = the reference's behaviour, no pivoting and no perturbation (L:2653); tol in (0, 1] switches on threshold partial
+ * pivoting inside the 64 x 64 diagonal blocks, perturb > 0 the replacement of pivots below perturb * max|a_ij| (see
+ * sf_lu_plan_set_pivoting).  sf_handlers_perturbed_pivots: perturbed pivots of the factorization that filled this host array
+ * (-1: unknown array; with several handlers a shared panel's perturbations are counted once per rank that stores it). */
+int sf_handlers_set_lu_pivoting(double tol, double perturb);
+int64_t sf_handlers_perturbed_pivots(const sf_float *Lsx_host);
+
+/* The struct path's solve with the RESIDENT factor: after SparseFrame_factorize the factor is still in the handler's cached plan (or
+ * spread over the handlers' plans); SparseFrame_solve_supernodal (which only receives matrix_info) asks here, by the address of the
+ * host copy.  Solves on the device(s) (b, x in the permuted numbering, n doubles each way) when the plan still holds THAT factorization
+ * (generation counter) AND the caller's array still is what the device holds: a 64-bit fingerprint of every panel -- sum over its
+ * values of bits(v) * (2 index + 1) * K mod 2^64, any single changed value changes it -- is computed over the WHOLE host array (one
+ * threaded pass, ~0.2 s for 30 GB) and compared with the device's (computed once per factorization, about one read of the factor).
+ * Otherwise returns SF_ERR_ARG and the caller solves on the host as the reference does (C:3036-3139).
+ * sf_handlers_set_resident_solve(mode): 0 = never (always the host sweep), 1 = verified as above (default), 2 = trusted: the caller
+ * guarantees it does not modify Lsx between factorize and solve; the comparison is skipped (0.03 s instead of 0.25 s at 128^3).
+ * SF_SOLVE=host in the environment forces the host solve.  forget: the host copy is being freed. */
+int sf_handlers_set_resident_solve(int mode);
+/* 1 if this build keeps the A/B environment switches of finished experiments (make EXP=1), 0 for a release build */
+int sf_build_experiments(void);
 int sf_handlers_solve_resident(const sf_float *Lsx_host, const sf_float *b, sf_float *x);
 /* the same with the symbolic arrays of the matrix at hand: after a factorization by SEVERAL handlers the factor is spread over
  * their plans; with these arrays the library can build a whole plan on the first handler's device, gather the panels into it

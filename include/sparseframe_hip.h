@@ -104,7 +104,8 @@ int SparseFrame_set_matrix_csc(struct matrix_info_struct *matrix_info, sf_long n
                                const sf_long *Cp, const sf_long *Ci, const sf_float *Cx, int isSymmetric);
 /* caller-supplied fill-reducing ordering (Perm[new] = old).  The reference calls
  * METIS_NodeND here (C:1937), which is third-party and unpinned; when no ordering is
- * supplied SparseFrame_analyze uses the identity. */
+ * supplied SparseFrame_analyze orders with the built-in nested dissection (permMethod = PERM_METIS is what
+ * SparseFrame_initialize_matrix sets, as the reference always orders); perm == NULL here selects the natural order. */
 int SparseFrame_set_perm(struct matrix_info_struct *matrix_info, const sf_long *perm);
 
 /* replaces C:1916-1978: perm -> etree -> postorder -> colcount -> postorder ->

@@ -98,7 +98,8 @@ int SparseFrame_set_matrix_csc(struct matrix_info_struct *matrix_info, sf_long n
                                const sf_long *Cp, const sf_long *Ci, const sf_float *Cx, int isSymmetric);
 /* caller-supplied fill-reducing ordering (Perm[new] = old).  The reference calls
  * METIS_NodeND here (L:2398), which is third-party and unpinned; when no ordering is
- * supplied SparseFrame_analyze uses the identity. */
+ * supplied SparseFrame_analyze orders with the built-in nested dissection (permMethod = PERM_METIS is what
+ * SparseFrame_initialize_matrix sets, as the reference always orders); perm == NULL here selects the natural order. */
 int SparseFrame_set_perm(struct matrix_info_struct *matrix_info, const sf_long *perm);
 
 /* replaces L:2233-2458: perm -> etree -> postorder -> colcount -> postorder ->
@@ -111,6 +112,20 @@ int SparseFrame_analyze(struct common_info_struct *common_info, struct matrix_in
  * Returns 0 on success, SF_ERR_* otherwise (the reference always returns 0). */
 int SparseFrame_factorize(struct common_info_struct *common_info, struct gpu_info_struct *gpu_info_list, struct matrix_info_struct *matrix_info);
 int SparseFrame_factorize_supernodal(struct common_info_struct *common_info, struct gpu_info_struct *gpu_info_list, struct matrix_info_struct *matrix_info);
+
+/* Pivoting -- NOT in the reference, which never pivots (magma_dgetrf_nopiv L:2653, devIpiv = NULL L:3344; its static pre-pivot
+ * L:589-673 is compiled out at L:784).  DEFAULT = the reference's behaviour: no interchanges, no perturbation, matrix_info->Lsx is
+ * the reference's factor and matrix_info->PivInv the identity.  SparseFrame_set_pivoting(tol, perturb) (process-wide, before
+ * SparseFrame_factorize; or SF_LU_PIVOT_TOL in the environment) opts in to threshold partial pivoting inside the 64 x 64 diagonal
+ * blocks of a supernode (tol in (0, 1], 1 = partial pivoting) and to the replacement of pivots below perturb * max|a_ij| by that
+ * value.  CONTRACT when it is on: PivInv[g] = the row position original row g was given (same 64-column block; identity where
+ * nothing moved); a row's entries in its block's own columns and to the right moved with it, the L entries LEFT of the block did
+ * not -- a consumer of Lsx must apply the interchanges block by block in its forward sweep (LINPACK-style), as
+ * SparseFrame_solve_supernodal here does; a consumer that ignores PivInv gets a wrong x whenever PivInv is not the identity.
+ * SparseFrame_perturbed_pivots: how many pivots the last factorization into this matrix_info's Lsx replaced (0 = the factor is
+ * exact; > 0: refine the solution iteratively; -1 unknown). */
+int SparseFrame_set_pivoting(double tol, double perturb);
+sf_long SparseFrame_perturbed_pivots(const struct matrix_info_struct *matrix_info);
 
 /* replaces L:3592-3700 (host triangular solves, reads Lsx/Bx, writes Xx) */
 int SparseFrame_solve_supernodal(struct matrix_info_struct *matrix_info);

@@ -201,3 +201,44 @@ def lu_residual(sym, Lsx):
                             int(g("nsuper")), *[a.ctypes.data_as(_lp) for a in arrs],
                             Lsx.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
     return float(r), x[:int(g("n"))]
+
+
+# ---------------------------------------------------------------------------------------------
+# LU with threshold pivoting inside the 64 x 64 diagonal blocks (the product's own rule restated in scalar C: the reference
+# never pivots, LU/Source/SparseFrame.c:2653, :3344, :589-673 disabled -- PARITY UNPINNED by construction)
+# ---------------------------------------------------------------------------------------------
+def lu_factorize_pivot(sym, tol=0.1, perturb=1.4901161193847656e-08):
+    """Returns (Lsx in the reference's packed layout, info, pivpos, pivinv, perturbed_pivots).  `perturb` is relative to
+    max |a_ij| of the analysed matrix, as in the product (sf_lu_plan_set_pivoting)."""
+    lib = _load()
+    g = _getter(sym)
+    arrs = [_i64(g(k)) for k in ("Super", "SuperMap", "Lsip", "Lsi", "Lsxp", "Lp", "Li")]
+    Lx = _f64(g("Lx"))
+    Up, Ui, Ux = _u_arrays(g)
+    LeafQueue = _i64(g("LeafQueue"))
+    n = int(g("n"))
+    amax = max(float(np.abs(Lx).max()) if len(Lx) else 0.0, float(np.abs(Ux).max()) if len(Ux) else 0.0)
+    Lsx = np.empty(max(int(g("xsize")), 1), dtype=np.float64)
+    pivpos = np.arange(max(n, 1), dtype=np.int64)
+    pivinv = np.arange(max(n, 1), dtype=np.int64)
+    nper = np.zeros(1, dtype=np.int64)
+    lib.sfo_lu_factorize_pivot.restype = C.c_int
+    info = lib.sfo_lu_factorize_pivot(C.c_int64(n), C.c_int64(int(g("nsuper"))), *[a.ctypes.data_as(_lp) for a in arrs],
+                                      Lx.ctypes.data_as(_dp), Up.ctypes.data_as(_lp), Ui.ctypes.data_as(_lp), Ux.ctypes.data_as(_dp),
+                                      LeafQueue.ctypes.data_as(_lp), C.c_int64(int(g("nsleaf"))), C.c_int64(int(g("csize"))),
+                                      C.c_double(float(tol)), C.c_double(float(perturb) * amax),
+                                      Lsx.ctypes.data_as(_dp), pivpos.ctypes.data_as(_lp), pivinv.ctypes.data_as(_lp),
+                                      nper.ctypes.data_as(_lp))
+    return Lsx[:int(g("xsize"))], int(info), pivpos[:n], pivinv[:n], int(nper[0])
+
+
+def lu_solve_pivot(sym, Lsx, pivpos, b):
+    lib = _load()
+    g = _getter(sym)
+    arrs = [_i64(g(k)) for k in ("Super", "Lsip", "Lsi", "Lsxp")]
+    Lsx, b, pivpos = _f64(Lsx), _f64(b), _i64(pivpos)
+    x = np.empty_like(b)
+    lib.sfo_lu_solve_pivot.restype = None
+    lib.sfo_lu_solve_pivot(C.c_int64(int(g("nsuper"))), *[a.ctypes.data_as(_lp) for a in arrs], Lsx.ctypes.data_as(_dp),
+                           pivpos.ctypes.data_as(_lp), C.c_int64(int(g("n"))), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    return x

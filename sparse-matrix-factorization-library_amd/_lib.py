@@ -88,6 +88,20 @@ lib.sf_chol_plan_solve_distributed.argtypes = [C.c_void_p, C.c_void_p, c_double_
 lib.sf_chol_plan_solve_distributed.restype = C.c_int
 lib.sf_handlers_replica_mismatches.argtypes = [C.c_void_p]
 lib.sf_handlers_replica_mismatches.restype = C.c_int64
+lib.sf_handlers_set_lu_pivoting.argtypes = [C.c_double, C.c_double]
+lib.sf_handlers_set_lu_pivoting.restype = C.c_int
+lib.sf_handlers_perturbed_pivots.argtypes = [C.c_void_p]
+lib.sf_handlers_perturbed_pivots.restype = C.c_int64
+lu_lib.SparseFrame_set_pivoting.argtypes = [C.c_double, C.c_double]
+lu_lib.SparseFrame_set_pivoting.restype = C.c_int
+lu_lib.SparseFrame_perturbed_pivots.argtypes = [C.c_void_p]
+lu_lib.SparseFrame_perturbed_pivots.restype = C.c_int64
+lib.sf_build_experiments.argtypes = []
+lib.sf_build_experiments.restype = C.c_int
+lib.sf_test_inject_failure.argtypes = [C.c_int, C.c_int]
+lib.sf_test_inject_failure.restype = None
+lib.sf_handlers_set_resident_solve.argtypes = [C.c_int]
+lib.sf_handlers_set_resident_solve.restype = C.c_int
 lib.sf_handlers_resident_solves.argtypes = []
 lib.sf_handlers_resident_solves.restype = C.c_int64
 lib.sf_handlers_plan_builds.argtypes = [C.c_void_p, C.c_int]
@@ -176,7 +190,7 @@ lib.sf_lu_plan_destroy.argtypes = [C.c_void_p]
 lib.sf_lu_plan_destroy.restype = C.c_int
 
 ERR_NAMES = {0: "SF_OK", 1: "SF_ERR_ARG", 2: "SF_ERR_NO_DEVICE", 3: "SF_ERR_ALLOC",
-             4: "SF_ERR_NOT_POSDEF", 5: "SF_ERR_HIP"}
+             4: "SF_ERR_NOT_POSDEF", 5: "SF_ERR_HIP", 6: "SF_ERR_PEER"}
 
 
 def check(rc, what):

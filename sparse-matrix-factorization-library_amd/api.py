@@ -412,7 +412,8 @@ class LUPlan(_ShardedPlanMixin, _ValidateMixin):
 
     def set_pivoting(self, tol=0.1, perturb=1.4901161193847656e-08):
         """threshold partial pivoting inside the 64 x 64 diagonal blocks (tol in [0, 1]; 0 = none, the reference's behaviour)
-        and the perturbation of tiny pivots (relative to max|a_ij|; 0 = a zero pivot is an error)"""
+        and the perturbation of tiny pivots (relative to max|a_ij|; 0 = a zero pivot is an error).  A new plan has (0, 0): the
+        reference never pivots (L:2653)."""
         check(lib.sf_lu_plan_set_pivoting(self._h, float(tol), float(perturb)), "sf_lu_plan_set_pivoting")
 
     def get_pivots(self):
@@ -652,3 +653,11 @@ class LUMatrixInfo(MatrixInfo):
     """the same stage functions from the LU library (libsparseframe_lu_hip.so, LU struct layout)"""
     _lib = lu_lib
     _struct = LUMatrixInfoStruct
+
+    @staticmethod
+    def set_pivoting(tol=0.0, perturb=0.0):
+        """process-wide policy of the LU struct entry points (SparseFrame_set_pivoting): (0, 0) = the reference's behaviour"""
+        check(lu_lib.SparseFrame_set_pivoting(float(tol), float(perturb)), "SparseFrame_set_pivoting")
+
+    def perturbed_pivots(self):
+        return int(lu_lib.SparseFrame_perturbed_pivots(C.byref(self.c)))

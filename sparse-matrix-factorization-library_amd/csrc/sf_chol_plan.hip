@@ -71,7 +71,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_fill, p->d_solveT, p->d_solveT_list};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_status, p->d_fill, p->d_solveT, p->d_solveT_list};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -282,7 +282,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     std::vector<size_t> blk_ready(blk_first[nsuper], 0);
 
     int su_maxk = sf::SU_MAXK;              // SF_SU_MAXK: experiment knob
-    if (const char* env = getenv("SF_SU_MAXK")) su_maxk = atoi(env);
+    if (const char* env = sf_exp_env("SF_SU_MAXK")) su_maxk = atoi(env);
     int32_t n_flags = 0;
     int64_t max_diag_tasks = 0;     // k_step launches: scratch for the 16 x 16 inverses, 1024 doubles per diagonal task
     // steps of up to this many workgroups run as ONE k_step launch; beyond it (swarms of tiny panels at the bottom levels)
@@ -499,7 +499,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         }
                     }
                 }
-                if ((int64_t)gtasks.size() > g0) p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
+                if ((int64_t)gtasks.size() > g0) {
+                    p->launches.push_back(Launch{2, g0, (int)(gtasks.size() - g0)});
+                    // a chain step of a shared panel runs replicated on every rank of its group: no tile split by K, so that each target
+                    // element receives ONE addition and the replicas stay bit-identical (LU pivot decisions rest on that)
+                    p->launches.back().whole_tiles = shared && LS.share_cnt > 1;
+                }
                 if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
                 if ((int64_t)trsm.size() > t0) p->launches.push_back(Launch{1, t0, (int)(trsm.size() - t0)});
             }
@@ -620,17 +625,17 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
         const int tile = sf::SV_ROWS;
         // default: fused (35.3 ms at 128^3); SF_SOLVE_BWD_FUSED=0: two launches per backward step (38.2 ms)
-        const bool solve_diagT = !(getenv("SF_SOLVE_DIAGT") && atoi(getenv("SF_SOLVE_DIAGT")) == 0);
-        const bool bwd_ahead_env = !(getenv("SF_SOLVE_BWD_AHEAD") && atoi(getenv("SF_SOLVE_BWD_AHEAD")) == 0);
-        const bool bwd_fused = !(getenv("SF_SOLVE_BWD_FUSED") && atoi(getenv("SF_SOLVE_BWD_FUSED")) == 0);
+        const bool solve_diagT = !(sf_exp_env("SF_SOLVE_DIAGT") && atoi(sf_exp_env("SF_SOLVE_DIAGT")) == 0);
+        const bool bwd_ahead_env = !(sf_exp_env("SF_SOLVE_BWD_AHEAD") && atoi(sf_exp_env("SF_SOLVE_BWD_AHEAD")) == 0);
+        const bool bwd_fused = !(sf_exp_env("SF_SOLVE_BWD_FUSED") && atoi(sf_exp_env("SF_SOLVE_BWD_FUSED")) == 0);
         p->solve_bwd_fused = bwd_fused;
         const bool bwd_ahead = bwd_ahead_env && bwd_fused;
-        const bool fwd_ahead = !(getenv("SF_SOLVE_FWD_AHEAD") && atoi(getenv("SF_SOLVE_FWD_AHEAD")) == 0);
-        const bool fwd_far_first = !(getenv("SF_SOLVE_FWD_FAR_FIRST") && atoi(getenv("SF_SOLVE_FWD_FAR_FIRST")) == 0);
+        const bool fwd_ahead = !(sf_exp_env("SF_SOLVE_FWD_AHEAD") && atoi(sf_exp_env("SF_SOLVE_FWD_AHEAD")) == 0);
+        const bool fwd_far_first = !(sf_exp_env("SF_SOLVE_FWD_FAR_FIRST") && atoi(sf_exp_env("SF_SOLVE_FWD_FAR_FIRST")) == 0);
         int solve_far_wgs = 512;
-        if (const char* env = getenv("SF_SOLVE_FAR_WGS")) solve_far_wgs = std::max(1, atoi(env));
+        if (const char* env = sf_exp_env("SF_SOLVE_FAR_WGS")) solve_far_wgs = std::max(1, atoi(env));
         int solve_far_groups = 8;
-        if (const char* env = getenv("SF_SOLVE_FAR_GROUPS")) solve_far_groups = std::max(1, std::min(64, atoi(env)));
+        if (const char* env = sf_exp_env("SF_SOLVE_FAR_GROUPS")) solve_far_groups = std::max(1, std::min(64, atoi(env)));
         for (int l = 0; l < nlevels; ++l) {
             sf_long maxcol = 0;
             for (sf_long s : by_level[l]) maxcol = std::max(maxcol, Super[s + 1] - Super[s]);
@@ -793,11 +798,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // rank once factored: their pieces are dealt out over the ranks so that every PCIe link carries a share.
     {
         if (const char* env = getenv("SF_DL_WORKERS")) p->dl_workers = std::max(1, std::min(DL_WORKERS_MAX, atoi(env)));
-        if (const char* env = getenv("SF_DL_HOST_WAIT")) p->dl_host_wait = atoi(env) != 0;
+        if (const char* env = sf_exp_env("SF_DL_HOST_WAIT")) p->dl_host_wait = atoi(env) != 0;
         if (const char* env = getenv("SF_DL_SLOT_MB")) p->dl_slot = (int64_t)std::max(1, atoi(env)) << 17;
         const int64_t DL_SLOT = p->dl_slot;
         bool dl_2d = true;
-        if (const char* env = getenv("SF_DL_2D")) dl_2d = atoi(env) != 0;
+        if (const char* env = sf_exp_env("SF_DL_2D")) dl_2d = atoi(env) != 0;
         std::vector<DlPiece> runs;
         std::vector<uint32_t> run_mask;
         int last_phase = -2;
@@ -809,7 +814,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         // packed column longer than a staging slot): the older form, a gather kernel per piece on the worker's stream -- which has
         // to find free CUs next to the factorization's persistent kernels and made the LU struct call 2x its resident step.
         bool lu_direct = lu;
-        if (const char* env = getenv("SF_DL_LU_PACK"))
+        if (const char* env = sf_exp_env("SF_DL_LU_PACK"))
             if (atoi(env) != 0) lu_direct = false;
         for (sf_long s = 0; s < nsuper && lu_direct; ++s)
             if (XP[s] >= 0 && 2 * (Lsip[s + 1] - Lsip[s]) - (Super[s + 1] - Super[s]) > DL_SLOT) lu_direct = false;
@@ -966,7 +971,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         // ordinary streams.
         int prio_least = 0, prio_greatest = 0;
         bool prio = true;
-        if (const char* env = getenv("SF_STREAM_PRIORITY")) prio = atoi(env) != 0;
+        if (const char* env = sf_exp_env("SF_STREAM_PRIORITY")) prio = atoi(env) != 0;
         if (prio && (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess || prio_greatest >= prio_least)) {
             (void)hipGetLastError();
             prio = false;
@@ -1073,8 +1078,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             const size_t pb = (size_t)(2 * std::max<int64_t>(n, 1) + 1) * sizeof(int32_t);
             if (hipMalloc((void**)&p->d_piv, pb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += pb;
-            if (const char* env = getenv("SF_LU_PIVOT_TOL")) p->piv_tol = atof(env);
-            if (const char* env = getenv("SF_LU_PERTURB")) p->piv_perturb = atof(env);
+            if (const char* env = getenv("SF_LU_PIVOT_TOL")) {
+                p->piv_tol = std::min(1.0, std::max(0.0, atof(env)));
+                if (p->piv_tol > 0.0) p->piv_perturb = 1.4901161193847656e-08;      // sqrt(eps): pivoting comes with its fallback
+            }
+            if (const char* env = getenv("SF_LU_PERTURB")) p->piv_perturb = std::max(0.0, atof(env));
             if (!p->u_alias) {
                 if ((rc = upload(&p->d_Up, Up64, &p->bytes_device))) break;
                 if ((rc = upload(&p->d_Ui, Ui32, &p->bytes_device))) break;
@@ -1086,10 +1094,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         // GEMM launches: 8 claim counters each (one per XCD) for the dynamic deal of their whole-tile rounds
         for (Launch& L : p->launches)
             if (L.kind == 2 || L.kind == 3 || L.kind == 4) { L.ticket = p->n_tickets; p->n_tickets += 8; }
-        if (const char* env = getenv("SF_GEMM_DYNAMIC")) p->gemm_dynamic = atoi(env) != 0;
-        if (const char* env = getenv("SF_GEMM_WHOLE_TILES"))        // 0: replicated launches split tiles like the others (A/B only:
-            if (atoi(env) == 0)                                      // the ranks' copies of a shared panel then differ in the last bits)
-                for (Launch& L : p->launches) L.whole_tiles = false;
+        if (const char* env = sf_exp_env("SF_GEMM_DYNAMIC")) p->gemm_dynamic = atoi(env) != 0;
         // + 2 doubles: the GEMM stages row PAIRS with 16-byte loads and may touch 8 bytes past the last panel
         const size_t xb = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
@@ -1162,7 +1167,7 @@ static int create_mapped(sf_chol_plan** out, int device, bool lu, sf_long n, sf_
     // flops at 48 TFLOP/s (calibrated on tools/emulate_rank.py, 128^3 / 8 and 161^3 / 4); the root's divisible flops, at 58 TFLOP/s, are
     // then dealt out so that the ranks finish together (shares clamped to [0.2, 3] / nranks).  SF_WEIGHTED_SHARES=0: equal shares.
     std::vector<double> cum;
-    const char* wenv = getenv("SF_WEIGHTED_SHARES");
+    const char* wenv = sf_exp_env("SF_WEIGHTED_SHARES");
     if (nranks > 1 && !(wenv && atoi(wenv) == 0)) {
         const uint32_t all = nranks >= 32 ? 0xffffffffu : ((1u << nranks) - 1u);
         std::vector<double> before(nranks, 0.0);
@@ -1677,7 +1682,7 @@ static double dl_now() {
 // the stream priorities in plan_create), and a library should not move its caller's threads around without being asked.
 static void dl_lookup_cpus(sf_chol_plan* p) {
     p->dl_cpus_known = -1;
-    const char* pin_env = getenv("SF_DL_PIN");
+    const char* pin_env = sf_exp_env("SF_DL_PIN");
     if (!pin_env || atoi(pin_env) == 0) return;
     int node = -1;
     if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, p->device) != hipSuccess) { (void)hipGetLastError(); node = -1; }
@@ -1996,6 +2001,29 @@ int sf_chol_plan_get_factor_range(sf_chol_plan* p, sf_long e_begin, sf_long e_en
     hipError_t e3 = hipStreamSynchronize(p->stream);
     (void)hipFree(tmp);
     return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? SF_OK : SF_ERR_HIP;
+}
+
+int sf_plan_panel_hashes(sf_chol_plan* p, const uint64_t** out) {
+    if (!p || !out) return SF_ERR_ARG;
+    if (p->hash_epoch != p->epoch || p->h_hash.size() != (size_t)std::max<int64_t>(p->nsuper, 1)) {
+        HIP_TRY(hipSetDevice(p->device));
+        const size_t nb = (size_t)std::max<int64_t>(p->nsuper, 1) * sizeof(unsigned long long);
+        unsigned long long* d_h = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_h, nb));
+        const int64_t* xp = (p->lu || p->partial) ? p->d_Xp : p->d_Lsxp;
+        hipError_t e0 = hipMemsetAsync(d_h, 0, nb, p->stream);
+        sf::launch_factor_hash(p->d_Super, p->d_Lsip, xp, p->d_Lsxp, (int32_t)p->nsuper, p->d_Lsx, p->d_Lsx + p->xC, p->lu ? 1 : 0,
+                               p->xsize, d_h, p->stream);
+        hipError_t e1 = hipGetLastError();
+        p->h_hash.assign((size_t)std::max<int64_t>(p->nsuper, 1), 0);
+        hipError_t e2 = hipMemcpyAsync(p->h_hash.data(), d_h, nb, hipMemcpyDeviceToHost, p->stream);
+        hipError_t e3 = hipStreamSynchronize(p->stream);
+        (void)hipFree(d_h);
+        if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { p->hash_epoch = -1; return SF_ERR_HIP; }
+        p->hash_epoch = p->epoch;
+    }
+    *out = p->h_hash.data();
+    return SF_OK;
 }
 
 int sf_lu_plan_set_pivoting(sf_lu_plan* p, double tol, double perturb) {

@@ -10,6 +10,8 @@
 // matrix_info->Lsx WHILE the upper levels still compute (sf_chol_plan_factorize_to_host; reference C:2888-2895).
 #include <sparseframe_hip.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -101,6 +103,62 @@ struct Resident {
 std::mutex& g_res_mu = *new std::mutex();
 std::unordered_map<const void*, Resident>& g_resident = *new std::unordered_map<const void*, Resident>();
 int64_t g_resident_solves = 0;      // solves served from a resident factor (tests)
+// LU pivoting policy of the struct entry points (sf_handlers_set_lu_pivoting): unset = whatever the plans were created with (the
+// reference's behaviour, no pivoting, unless SF_LU_PIVOT_TOL said otherwise); g_last_perturbed: count of the last LU factorization
+std::mutex& g_piv_mu = *new std::mutex();
+bool g_piv_set = false;
+double g_piv_tol = 0.0, g_piv_perturb = 0.0;
+std::unordered_map<const void*, int64_t>& g_perturbed = *new std::unordered_map<const void*, int64_t>();
+int apply_pivot_policy(sf_chol_plan* plan) {
+    std::lock_guard<std::mutex> g(g_piv_mu);
+    return (g_piv_set && plan && plan->lu) ? sf_lu_plan_set_pivoting(plan, g_piv_tol, g_piv_perturb) : SF_OK;
+}
+void note_perturbed(const void* Lsx, int64_t count) {
+    std::lock_guard<std::mutex> g(g_piv_mu);
+    if (g_perturbed.size() > 4096) g_perturbed.clear();
+    g_perturbed[Lsx] = count;
+}
+// resident-solve policy (sf_handlers_set_resident_solve): 0 never, 1 after a FULL comparison of fingerprints (default), 2 trusted
+std::atomic<int> g_resident_mode{1};
+
+// The fingerprint of k_factor_hash over the caller's host array: H[s] = sum of bits(v_e) * (2 e + 1) * K over the values of panel s.
+// Worker threads pull 32 MiB chunks from a counter and walk them with the supernode of the current value (one multiply per word:
+// memory-bound); the per-chunk partial sums are merged under a lock.
+void host_panel_hashes(const double* Lsx, const int64_t* Lsxp, int64_t nsuper, std::vector<uint64_t>& out) {
+    out.assign((size_t)std::max<int64_t>(nsuper, 1), 0);
+    const int64_t total = nsuper > 0 ? Lsxp[nsuper] : 0;
+    if (total <= 0) return;
+    const int64_t CH = (int64_t)4 << 20;
+    const int64_t nch = (total + CH - 1) / CH;
+    int T = (int)std::min<int64_t>(nch, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    if (const char* e = getenv("SF_VERIFY_THREADS")) T = std::max(1, std::min(64, atoi(e)));
+    std::atomic<int64_t> next{0};
+    std::mutex mu;
+    auto work = [&] {
+        std::vector<std::pair<int64_t, uint64_t>> loc;
+        const uint64_t K = 0x9E3779B97F4A7C15ull;
+        for (int64_t c = next.fetch_add(1); c < nch; c = next.fetch_add(1)) {
+            const int64_t b = c * CH, e_end = std::min(total, b + CH);
+            int64_t s = std::upper_bound(Lsxp, Lsxp + nsuper + 1, b) - Lsxp - 1;
+            int64_t e = b;
+            while (e < e_end) {
+                while (e >= Lsxp[s + 1]) ++s;
+                const int64_t stop = std::min(e_end, Lsxp[s + 1]);
+                uint64_t acc = 0, m = (2ull * (uint64_t)e + 1ull) * K;
+                const uint64_t* w = reinterpret_cast<const uint64_t*>(Lsx);
+                for (; e < stop; ++e, m += 2ull * K) acc += w[e] * m;
+                if (acc) loc.emplace_back(s, acc);
+            }
+        }
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& pr : loc) out[(size_t)pr.first] += pr.second;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+}
+
 void forget_plan(sf_chol_plan* plan) {
     std::lock_guard<std::mutex> g(g_res_mu);
     for (auto it = g_resident.begin(); it != g_resident.end();) {
@@ -218,6 +276,8 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
         }
     for (int r = 0; r < N; ++r) forget_plan(entry->plans[r]);       // the host copies these plans' factors stood for are history
     for (int r = 0; r < N; ++r)
+        if (int rc = apply_pivot_policy(entry->plans[r])) return rc;
+    for (int r = 0; r < N; ++r)
         th.emplace_back([&, r] { rcs[r] = sf_chol_plan_factorize_distributed(entry->plans[r], M.comms[r], Lsx_out, 1); });
     for (std::thread& t : th) t.join();
     for (int r = 0; r < N; ++r)
@@ -225,6 +285,11 @@ static int factorize_all_handlers(struct common_info_struct* common, struct gpu_
     if (lu && PivOut)      // every rank reports the blocks of the panels it stores (the top panels' records agree on all ranks)
         for (int r = 0; r < N; ++r)
             if (int rc = sf_lu_plan_get_pivots(entry->plans[r], PivOut)) return rc;
+    if (lu) {              // (a shared top panel's perturbations are counted by every rank of its group: an upper bound, 0 is exact)
+        int64_t per = 0;
+        for (int r = 0; r < N; ++r) per += entry->plans[r]->last_perturbed;
+        note_perturbed(Lsx_out, per);
+    }
     {
         // the factor is now spread over the ranks' plans; a solve of the struct path may gather it into a whole plan on the first
         // handler's device (sf_handlers_solve_resident)
@@ -381,8 +446,10 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
     }
     const auto tk2 = std::chrono::steady_clock::now();
     forget_plan(plan);              // whatever host copy this plan's factor stood for is about to be overwritten on the device
-    int rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
+    int rc = apply_pivot_policy(plan);
+    if (!rc) rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
     if (!rc && lu && PivOut) rc = sf_lu_plan_get_pivots(plan, PivOut);
+    if (!rc && lu) note_perturbed(Lsx_out, plan->last_perturbed);
     if (!rc) {
         Resident R;
         R.plan = plan;
@@ -413,6 +480,8 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
     auto why = [&](const char* m) { if (trace) fprintf(stderr, "[sparseframe-hip] resident solve not used: %s\n", m); return SF_ERR_ARG; };
     if (const char* e = getenv("SF_SOLVE"))
         if (!strcmp(e, "host")) return SF_ERR_ARG;
+    const int mode = g_resident_mode.load();
+    if (mode == 0) return SF_ERR_ARG;
     std::lock_guard<std::mutex> g(g_res_mu);
     auto it = g_resident.find((const void*)Lsx_host);
     if (it == g_resident.end()) return why("no resident factor is registered for this Lsx");
@@ -430,28 +499,21 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
         bool distributed = true;
         if (const char* e = getenv("SF_SOLVE")) distributed = strcmp(e, "gather") != 0;
         if (distributed && R.comms.size() == R.parts.size()) {
-            // the host copy must still be what the devices hold: the first window of the first panel each of three ranks stores
-            // (Cholesky: a stored panel is a contiguous run in both layouts; LU panels are packed on the way out, not compared here)
+            // the host copy must still be what the devices hold: EVERY panel's fingerprint over the caller's array against the one
+            // every rank that stores the panel computes over its own copy (k_factor_hash; Cholesky and LU)
             const size_t N = R.parts.size();
-            if (!R.parts[0]->lu && Lsxp) {
-                for (size_t r : {(size_t)0, N / 2, N - 1}) {
-                    sf_chol_plan* P = R.parts[r];
-                    sf_long s0 = 0;
-                    while (s0 < P->nsuper && P->h_XP[s0] < 0) ++s0;
-                    if (s0 >= P->nsuper) continue;
-                    const sf_long w = std::min<sf_long>(512, Lsxp[s0 + 1] - Lsxp[s0]);
-                    std::vector<double> dev((size_t)w);
-                    if (hipSetDevice(P->device) != hipSuccess ||
-                        hipMemcpy(dev.data(), P->d_Lsx + P->h_XP[s0], (size_t)w * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-                        return why("reading a rank's panel failed");
-                    double amax = 0.0, dmax = 0.0;
-                    for (sf_long i = 0; i < w; ++i) {
-                        const double h = Lsx_host[Lsxp[s0] + i], d = dev[(size_t)i];
-                        if (!(h == h) || !(d == d)) continue;
-                        amax = std::max(amax, std::fabs(h));
-                        dmax = std::max(dmax, std::fabs(h - d));
-                    }
-                    if (!(dmax <= 1e-10 * amax)) { g_resident.erase(it); return why("the host copy differs from a rank's panel (sampled)"); }
+            if (mode == 1) {
+                sf_chol_plan* P0 = R.parts[0];
+                std::vector<uint64_t> hh;
+                host_panel_hashes(Lsx_host, P0->h_Lsxp.data(), P0->nsuper, hh);
+                for (size_t r = 0; r < N; ++r) {
+                    const uint64_t* dh = nullptr;
+                    if (sf_plan_panel_hashes(R.parts[r], &dh) != SF_OK) return why("a rank's fingerprints could not be computed");
+                    for (int64_t sn = 0; sn < P0->nsuper; ++sn)
+                        if (R.parts[r]->h_XP[sn] >= 0 && dh[sn] != hh[(size_t)sn]) {
+                            g_resident.erase(it);
+                            return why("the host copy differs from a rank's panel (fingerprint)");
+                        }
                 }
             }
             std::vector<int> rcs(N, SF_OK);
@@ -484,30 +546,19 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
         g_resident.erase(it);
         return why("the plan holds a later factorization");
     }
-    // the host copy must still be what the device holds (it came from there bit by bit): three windows of 512 values
-    const sf_long xs = plan->xsize, w = std::min<sf_long>(512, xs);
-    const sf_long starts[3] = {0, std::max<sf_long>(0, xs / 2 - w / 2), xs - w};
-    std::vector<double> dev((size_t)w);
-    // (a gathered factor: the host piece of a shared panel may come from another rank than the gathered one.  The ranks' copies are
-    // bit-identical by construction (whole_tiles, see plan_create) unless SF_GEMM_WHOLE_TILES=0 asked otherwise: compare to 1e-10)
-    const bool exact = R.parts.empty();
-    for (sf_long st : starts) {
-        bool same = sf_chol_plan_get_factor_range(plan, st, st + w, dev.data()) == SF_OK;
-        if (same && exact) same = memcmp(dev.data(), Lsx_host + st, (size_t)w * sizeof(double)) == 0;
-        if (same && !exact) {
-            double amax = 0.0, dmax = 0.0;
-            for (sf_long i = 0; i < w; ++i) {
-                const double h = Lsx_host[st + i], d = dev[(size_t)i];
-                if (!(h == h) || !(d == d)) continue;          // entries the layout does not define (never written) may be anything
-                amax = std::max(amax, std::fabs(h));
-                dmax = std::max(dmax, std::fabs(h - d));
+    // the host copy must still be what the device holds (it came from there bit by bit): the fingerprint of every panel of the
+    // caller's array against the device's (one pass over the host array, threaded; the device side is cached per factorization)
+    if (mode == 1) {
+        if (!R.parts.empty()) plan->hash_epoch = -1;        // a gathered plan: its content changes without a factorization of its own
+        const uint64_t* dh = nullptr;
+        if (sf_plan_panel_hashes(plan, &dh) != SF_OK) return why("the device fingerprints could not be computed");
+        std::vector<uint64_t> hh;
+        host_panel_hashes(Lsx_host, plan->h_Lsxp.data(), plan->nsuper, hh);
+        for (int64_t sn = 0; sn < plan->nsuper; ++sn)
+            if (dh[sn] != hh[(size_t)sn]) {
+                g_resident.erase(it);
+                return why("the host copy differs from the device's (fingerprint)");
             }
-            same = dmax <= 1e-10 * amax;
-        }
-        if (!same) {
-            g_resident.erase(it);
-            return why("the host copy differs from the device's (sampled)");
-        }
     }
     const int rc = plan->lu ? sf_lu_plan_solve(plan, b, x) : sf_chol_plan_solve(plan, b, x);
     if (!rc) ++g_resident_solves;
@@ -561,8 +612,42 @@ int64_t sf_handlers_resident_solves(void) {
 
 void sf_handlers_forget(const sf_float* Lsx_host) {
     if (!Lsx_host) return;
-    std::lock_guard<std::mutex> g(g_res_mu);
-    g_resident.erase((const void*)Lsx_host);
+    {
+        std::lock_guard<std::mutex> g(g_res_mu);
+        g_resident.erase((const void*)Lsx_host);
+    }
+    std::lock_guard<std::mutex> g(g_piv_mu);
+    g_perturbed.erase((const void*)Lsx_host);
+}
+
+// 1 when the library was built with the A/B switches of finished experiments (make EXP=1), 0 for a release build
+int sf_build_experiments(void) {
+#ifdef SF_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int sf_handlers_set_resident_solve(int mode) {
+    if (mode < 0 || mode > 2) return SF_ERR_ARG;
+    g_resident_mode.store(mode);
+    return SF_OK;
+}
+
+int sf_handlers_set_lu_pivoting(double tol, double perturb) {
+    if (!(tol >= 0.0) || tol > 1.0 || !(perturb >= 0.0)) return SF_ERR_ARG;
+    std::lock_guard<std::mutex> g(g_piv_mu);
+    g_piv_set = true;
+    g_piv_tol = tol;
+    g_piv_perturb = perturb;
+    return SF_OK;
+}
+
+int64_t sf_handlers_perturbed_pivots(const sf_float* Lsx_host) {
+    std::lock_guard<std::mutex> g(g_piv_mu);
+    auto it = g_perturbed.find((const void*)Lsx_host);
+    return it == g_perturbed.end() ? -1 : it->second;
 }
 
 int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_allocate(common, list); }

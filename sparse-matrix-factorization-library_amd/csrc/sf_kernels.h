@@ -3,6 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include <cstdlib>
+// A/B switches of finished experiments (the alternative each one selects lost its measurement: DESIGN "Environment variables") are
+// compiled OUT of release builds -- `make EXP=1` (-DSF_EXPERIMENTS) brings them back for re-measuring; sf_build_experiments() tells.
+static inline const char* sf_exp_env(const char* name) {
+#ifdef SF_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 namespace sf {
 
 constexpr int NB = 64;          // diagonal block size of the in-panel right-looking factorization
@@ -117,6 +129,8 @@ void launch_getrf(const PotrfTask* tasks, int ntasks, double* Lsx, int64_t u_shi
 // receives the reference's packed L11 \ U11 (L:2514-2517).  One workgroup per 64 x 64 tile: rows [r0, r0 + 64), columns
 // [max(c0, cb), min(c0 + 64, ce)), transposed through LDS.  Nothing reads that part of an L panel (the solves mask it by index).
 struct FillTile { int64_t xp; int32_t nsrow, r0, c0, cb, ce; };
+void launch_factor_hash(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
+                        const double* PL, const double* PU, int lu, int64_t total, unsigned long long* H, hipStream_t st);
 void launch_lu_fill_u11(const FillTile* tiles, int64_t ntiles, double* PL, const double* PU, hipStream_t st);
 void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
                     const double* PL, const double* PU, double* out, int64_t e_begin, int64_t e_end, hipStream_t st);

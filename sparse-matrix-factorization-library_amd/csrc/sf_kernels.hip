@@ -292,6 +292,64 @@ void launch_pack_lu(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp
                        Super, Lsip, Xp, RefXp, nsuper, PL, PU, out, e_begin, e_end);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fingerprint of the factor as the HOST sees it (reference layout), one 64-bit word per supernode:
+//   H[s] = sum over the values e of panel s of  bits(v_e) * (2 e + 1) * K   (mod 2^64),  e = index in the reference layout.
+// Order-independent (a sum), position-dependent (odd multiplier per index), a changed value always changes it, zeros add nothing.
+// The struct path's solve compares it with the same sum over the caller's host array before it trusts the resident factor
+// (sf_handlers.hip).  A workgroup walks a contiguous range of `chunk` values; a thread keeps the supernode of its current value
+// (monotone walk) and flushes its partial sum when the supernode changes.  LU: the value is gathered from the (L, U^T) panel pair
+// exactly as k_pack_lu does, so the result does not depend on which block columns k_lu_fill_u11 has touched.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_factor_hash(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsip, const int64_t* __restrict__ Xp,
+              const int64_t* __restrict__ RefXp, int32_t nsuper, const double* __restrict__ PL, const double* __restrict__ PU, int lu,
+              int64_t total, int64_t chunk, unsigned long long* __restrict__ H) {
+    const int64_t begin = (int64_t)blockIdx.x * chunk, end = min(begin + chunk, total);
+    int64_t e = begin + threadIdx.x;
+    if (e >= end) return;
+    int lo = 0, hi = nsuper;                // largest s with RefXp[s] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (RefXp[mid] <= e) lo = mid; else hi = mid;
+    }
+    int s = lo;
+    unsigned long long acc = 0;
+    int64_t s_end = RefXp[s + 1], s_beg = RefXp[s], xp = Xp[s];
+    int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+    for (; e < end; e += 256) {
+        if (e >= s_end) {
+            if (acc) atomicAdd(&H[s], acc);
+            acc = 0;
+            while (e >= RefXp[s + 1]) ++s;
+            s_end = RefXp[s + 1]; s_beg = RefXp[s]; xp = Xp[s];
+            nscol = Super[s + 1] - Super[s]; nsrow = Lsip[s + 1] - Lsip[s];
+        }
+        if (xp < 0) continue;               // not stored on this rank
+        const int64_t off = e - s_beg;
+        double v;
+        if (!lu) {
+            v = PL[xp + off];
+        } else {
+            const int64_t lda = 2 * nsrow - nscol;
+            const int64_t j = off / lda, R = off % lda;
+            if (R < nscol) v = (R > j) ? PL[xp + j * nsrow + R] : PU[xp + j + R * nsrow];
+            else if (R < nsrow) v = PL[xp + j * nsrow + R];
+            else v = PU[xp + (R - nsrow + nscol) + j * nsrow];
+        }
+        acc += (unsigned long long)__double_as_longlong(v) * ((2ull * (unsigned long long)e + 1ull) * 0x9E3779B97F4A7C15ull);
+    }
+    if (acc) atomicAdd(&H[s], acc);
+}
+
+void launch_factor_hash(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
+                        const double* PL, const double* PU, int lu, int64_t total, unsigned long long* H, hipStream_t st) {
+    if (total <= 0 || nsuper <= 0) return;
+    const int64_t chunk = 256 * 64;
+    const int64_t blocks = (total + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_factor_hash, dim3((unsigned)blocks), dim3(256), 0, st, Super, Lsip, Xp, RefXp, nsuper, PL, PU, lu, total, chunk, H);
+}
+
 __global__ void __launch_bounds__(256)
 k_lu_fill_u11(const FillTile* __restrict__ tiles, double* __restrict__ PL, const double* __restrict__ PU) {
     __shared__ double tile[64][65];
@@ -1900,7 +1958,7 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
     const uint32_t grid = units < (uint32_t)GEMM_GRID ? units : (uint32_t)GEMM_GRID;
     // LDS-DMA staging is the default (68.9 vs 67.4 TFLOP/s at 16k x 16k x 4k, 552 vs 554 ms at 128^3); SF_GEMM_DMA=0 selects the
     // register-staged form (read per launch: the tests flip it)
-    const char* e = getenv("SF_GEMM_DMA");
+    const char* e = sf_exp_env("SF_GEMM_DMA");
     const bool dma = e ? atoi(e) != 0 : true;
     if (dma) {
         if (mode == 1)

@@ -190,6 +190,7 @@ int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_st
     SF_FREE(Super); SF_FREE(SuperMap); SF_FREE(Sparent); SF_FREE(LeafQueue);
     SF_FREE(Lsip); SF_FREE(Lsxp); SF_FREE(Lsi); SF_FREE(Lsx);
     SF_FREE(ST_Map); SF_FREE(ST_Pointer); SF_FREE(ST_Index); SF_FREE(Aoffset); SF_FREE(Moffset);
+    SF_FREE(PivInv);            // sized by nrow at the next factorization (a re-analysis may follow a read of a larger matrix)
 
     mi->Lp = dup_long(S, "Lp"); mi->Li = dup_long(S, "Li"); mi->Lx = dup_float(S, "Lx");
     mi->LTp = dup_long(S, "LTp"); mi->LTi = dup_long(S, "LTi"); mi->LTx = dup_float(S, "LTx");
@@ -233,6 +234,12 @@ int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct g
     return sf_handlers_factorize(common, list, 1, mi->serial, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi,
                                  mi->Lsxp, mi->Lp, mi->Li, mi->isSymmetric ? nullptr : mi->Up, mi->isSymmetric ? nullptr : mi->Ui,
                                  mi->Lx, mi->isSymmetric ? nullptr : mi->Ux, mi->Lsx, mi->PivInv);
+}
+
+// Pivoting is opt-in: by default the factor is the reference's (no interchanges, PivInv = identity, nothing perturbed).
+int SparseFrame_set_pivoting(double tol, double perturb) { return sf_handlers_set_lu_pivoting(tol, perturb); }
+sf_long SparseFrame_perturbed_pivots(const struct matrix_info_struct* mi) {
+    return (mi && mi->Lsx) ? (sf_long)sf_handlers_perturbed_pivots(mi->Lsx) : -1;
 }
 
 int SparseFrame_factorize(struct common_info_struct* common, struct gpu_info_struct* list, struct matrix_info_struct* mi) {

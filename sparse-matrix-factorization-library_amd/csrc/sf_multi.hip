@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -37,6 +38,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional
     ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -60,6 +62,7 @@ RcclApi& rccl() {
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
         api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.handle, "ncclCommInitAll");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+        api.CommAbort = (decltype(api.CommAbort))dlsym(api.handle, "ncclCommAbort");
         api.CommSplit = (decltype(api.CommSplit))dlsym(api.handle, "ncclCommSplit");
         api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
         api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
@@ -91,7 +94,7 @@ struct LocalGroup {
     hipEvent_t ev_ready[LOCAL_MAX] = {}, ev_done[LOCAL_MAX] = {};
     hipEvent_t ev_sum = nullptr;
     int refs = 0;
-    bool failed = false;
+    uint64_t failed_op = 0;         // number of the last collective a member failed in (0 = none): a failure does not outlive its collective
     std::vector<std::pair<uint32_t, LocalGroup*>> children;      // sub-groups by rank mask (guarded by mu)
     void barrier() {
         std::unique_lock<std::mutex> g(mu);
@@ -120,6 +123,8 @@ struct sf_comm {
     int device = 0;
     ncclComm_t nccl = nullptr;
     LocalGroup* local = nullptr;
+    uint64_t ops = 0;                   // LOCAL: collectives this member has taken part in (the members advance in lockstep)
+    bool dead = false;                  // RCCL: aborted after a failure in the middle of a run; every later call fails at once
     // sub-communicators of the groups of a proportionally mapped factorization, by the mask of WORLD ranks they hold
     std::vector<std::pair<uint32_t, sf_comm*>> subs;
     std::vector<uint32_t> prepared;     // every mask a collective split has been made for (member or not)
@@ -130,13 +135,18 @@ namespace {
 int local_allreduce(sf_comm* c, double* buf, int64_t count, hipStream_t st) {
     LocalGroup& G = *c->local;
     const int r = c->rank, n = G.n;
+    const uint64_t op = ++c->ops;
+    // (max / >=: a failure in the NEXT collective, set by a member that is already past this one's last barrier, may be seen here too;
+    // that errs on the side of reporting)
+    auto fail = [&] { std::lock_guard<std::mutex> g(G.mu); G.failed_op = std::max(G.failed_op, op); };
+    auto failed = [&] { std::lock_guard<std::mutex> g(G.mu); return G.failed_op >= op; };
     G.bufs[r] = buf;
     G.counts[r] = count;
     // count < 0: this rank has failed and only keeps the hand-shake going so that the others do not wait for ever
     bool ok = count >= 0 && hipEventRecord(G.ev_ready[r], st) == hipSuccess;
-    if (!ok) { std::lock_guard<std::mutex> g(G.mu); G.failed = true; }
+    if (!ok) fail();
     G.barrier();
-    { std::lock_guard<std::mutex> g(G.mu); ok = ok && !G.failed; }
+    ok = ok && !failed();
     if (r == 0) {
         for (int q = 1; q < n && ok; ++q) {
             ok = ok && G.counts[q] == count;        // every rank reduces the same segment
@@ -150,20 +160,20 @@ int local_allreduce(sf_comm* c, double* buf, int64_t count, hipStream_t st) {
             ok = hipGetLastError() == hipSuccess;
         }
         ok = ok && hipEventRecord(G.ev_sum, st) == hipSuccess;
+        if (!ok) fail();
     }
     G.barrier();
+    ok = ok && !failed();
     if (r > 0) {
         ok = ok && hipStreamWaitEvent(st, G.ev_sum, 0) == hipSuccess;
         if (ok && count > 0) ok = hipMemcpyAsync(buf, G.bufs[0], (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, st) == hipSuccess;
         ok = ok && hipEventRecord(G.ev_done[r], st) == hipSuccess;
     }
-    if (!ok) { std::lock_guard<std::mutex> g(G.mu); G.failed = true; }
+    if (!ok) fail();
     G.barrier();
     if (r == 0)
         for (int q = 1; q < n; ++q) ok = ok && hipStreamWaitEvent(st, G.ev_done[q], 0) == hipSuccess;
-    bool failed;
-    { std::lock_guard<std::mutex> g(G.mu); failed = G.failed; }
-    return (ok && !failed) ? SF_OK : SF_ERR_HIP;
+    return (ok && !failed()) ? SF_OK : SF_ERR_HIP;
 }
 
 }  // namespace
@@ -225,18 +235,19 @@ int sf_comm_prepare_groups(sf_comm* c, const uint32_t* masks, int nmasks) {
         // a mask met before (another plan with the same groups) needs no second split; every rank keeps the same list, so
         // the collective calls still match up
         if (std::find(c->prepared.begin(), c->prepared.end(), m) != c->prepared.end()) continue;
-        c->prepared.push_back(m);
+        // (recorded as prepared only once the sub-communicator exists: after a failed split the next call tries again, on every rank)
         const bool mine = ((m >> c->rank) & 1u) != 0;
         const int gsize = __builtin_popcount(m), grank = __builtin_popcount(m & ((1u << c->rank) - 1u));
         if (c->kind == 0) {
             ncclComm_t sub = nullptr;
             NCCL_TRY(rccl().CommSplit(c->nccl, mine ? 0 : NCCL_SPLIT_NOCOLOR, c->rank, &sub, nullptr));
+            c->prepared.push_back(m);
             if (!mine) continue;
             sf_comm* sc = new sf_comm();
             sc->kind = 0; sc->rank = grank; sc->nranks = gsize; sc->device = c->device; sc->nccl = sub;
             c->subs.push_back({m, sc});
         } else {
-            if (!mine) continue;
+            if (!mine) { c->prepared.push_back(m); continue; }
             LocalGroup* child = nullptr;
             {
                 std::lock_guard<std::mutex> g(c->local->mu);
@@ -248,12 +259,52 @@ int sf_comm_prepare_groups(sf_comm* c, const uint32_t* masks, int nmasks) {
                 }
             }
             if (!child) return SF_ERR_HIP;
+            c->prepared.push_back(m);
             sf_comm* sc = new sf_comm();
             sc->kind = 1; sc->rank = grank; sc->nranks = gsize; sc->device = c->device; sc->local = child;
             c->subs.push_back({m, sc});
         }
     }
     return SF_OK;
+}
+
+// test hook (sf_test_inject_failure): rank `g_fail_rank` fails once at point `g_fail_where` (1: before the first collective of a
+// distributed factorization, 2: in the middle of its segments, 3: before the first collective of a distributed solve, 4: in the
+// middle of its sweeps)
+static std::atomic<int> g_fail_rank{-1}, g_fail_where{0};
+static bool injected(int rank, int where) {
+    if (g_fail_where.load() != where || g_fail_rank.load() != rank) return false;
+    g_fail_where.store(0);
+    return true;
+}
+
+// A communicator that cannot go on (a failure between collectives of a running factorization or solve): RCCL peers may already sit
+// in kernels that wait for this rank, so the communicator and its sub-communicators are aborted (ncclCommAbort, when the library
+// has it) and marked dead -- every later call on them fails at once instead of enqueueing work nobody will match.
+static void abort_comm(sf_comm* c) {
+    if (!c || c->kind != 0 || c->dead) return;
+    c->dead = true;
+    for (auto& kv : c->subs) abort_comm(kv.second);
+    if (c->nccl && rccl().CommAbort) { (void)rccl().CommAbort(c->nccl); c->nccl = nullptr; }
+}
+
+// Every rank of `comm` learns whether ANY of them has failed so far: one 8-byte sum on `st`, waited for on the host.  Called by all
+// ranks whatever their own state, BEFORE the first data collective of a run, so that no rank enqueues collectives a failed peer
+// will never match (those would spin on the GPU for ever).  Returns my_rc if this rank failed, SF_ERR_PEER if only others did.
+static int agree_status(sf_chol_plan* p, sf_comm* comm, int my_rc, hipStream_t st) {
+    if (comm->nranks == 1) return my_rc;
+    bool ok = hipSetDevice(p->device) == hipSuccess;
+    if (ok && !p->d_status) ok = hipMalloc((void**)&p->d_status, sizeof(double)) == hipSuccess;
+    double flag = my_rc ? 1.0 : 0.0, got = 1.0;
+    ok = ok && hipMemcpyAsync(p->d_status, &flag, sizeof flag, hipMemcpyHostToDevice, st) == hipSuccess;
+    int rc;
+    if (ok) rc = sf_comm_allreduce_sum(comm, p->d_status, 1, st);
+    else rc = comm->kind == 1 ? (sf_comm_allreduce_sum(comm, nullptr, -1, st), SF_ERR_HIP) : SF_ERR_HIP;
+    if (!rc && (hipMemcpyAsync(&got, p->d_status, sizeof got, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)) rc = SF_ERR_HIP;
+    if (my_rc) return my_rc;
+    if (rc) return rc;
+    return got != 0.0 ? SF_ERR_PEER : SF_OK;
 }
 
 static sf_comm* group_comm(sf_comm* c, uint32_t mask) {
@@ -365,6 +416,7 @@ int sf_comm_destroy(sf_comm* c) {
 int sf_comm_allreduce_sum(sf_comm* c, void* device_buf, sf_long count, void* stream) {
     if (!c || (count > 0 && !device_buf)) return SF_ERR_ARG;
     if (count < 0 && c->kind != 1) return SF_ERR_ARG;
+    if (c->dead) return SF_ERR_PEER;
     if (c->kind == 1) return c->nranks == 1 ? SF_OK : local_allreduce(c, (double*)device_buf, count, (hipStream_t)stream);
     if (count == 0) return SF_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -387,33 +439,46 @@ int sf_chol_plan_solve_distributed(sf_chol_plan* p, sf_comm* comm, const sf_floa
     if (p->nranks == 1 && !p->partial) return sf_chol_plan_solve(p, b_host, x_host);
     int rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size());     // collective: before any early return
     if (rc) return rc;
-    if (p->solve_steps.empty()) return SF_OK;               // a rank that stores nothing (more ranks than subtrees) reports nothing
-    if (!p->d_solve || !p->d_x) return SF_ERR_ARG;
-    HIP_TRY(hipSetDevice(p->device));
-    hipStream_t st = p->stream;
+    // Everything that can fail on this rank alone happens BEFORE the first reduce, and the ranks agree on the outcome (a rank that
+    // stores nothing still takes part in the agreement): nobody enqueues a sum a failed peer will never join.
     const int64_t n = p->n;
-    if (n <= 0) return SF_OK;
-    // right-hand side: the columns this rank loads (the others start from zero: they only collect this rank's updates)
-    std::vector<double> xb((size_t)n, 0.0);
-    for (const auto& r : p->solve_load)
-        memcpy(xb.data() + r.first, b_host + r.first, (size_t)(r.second - r.first) * sizeof(double));
-    HIP_TRY(hipMemcpyAsync(p->d_x, xb.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    const bool idle = p->solve_steps.empty() || n <= 0;
+    hipStream_t st = p->stream;
+    std::vector<double> xb((size_t)std::max<int64_t>(n, 1), 0.0);
+    if (!idle && (!p->d_solve || !p->d_x)) rc = SF_ERR_ARG;
+    if (!rc && hipSetDevice(p->device) != hipSuccess) rc = SF_ERR_HIP;
+    const size_t nst = p->solve_steps.size();
+    if (!rc && !idle) {
+        // right-hand side: the columns this rank loads (the others start from zero: they only collect this rank's updates)
+        for (const auto& r : p->solve_load)
+            memcpy(xb.data() + r.first, b_host + r.first, (size_t)(r.second - r.first) * sizeof(double));
+        if (hipMemcpyAsync(p->d_x, xb.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) rc = SF_ERR_HIP;
+        if (!rc && p->d_solve_sync &&
+            hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + sf_chol_plan::SOLVE_TICKETS * nst) * sizeof(int), st) != hipSuccess)
+            rc = SF_ERR_HIP;
+    }
+    if (!rc && injected(p->rank, 3)) rc = SF_ERR_HIP;
+    if ((rc = agree_status(p, comm, rc, st))) return rc;
+    if (idle) return SF_OK;               // a rank that stores nothing (more ranks than subtrees) reports nothing
     const double* fwd_base = p->d_Lsx;
     const double* bwd_base = p->lu ? p->d_Lsx + p->xC : p->d_Lsx;
-    const size_t nst = p->solve_steps.size();
     int* sync = p->d_solve_sync + 1;
     int* tickets = sync + p->n_solve_sync;
-    if (p->d_solve_sync) HIP_TRY(hipMemsetAsync(p->d_solve_sync, 0, (size_t)(1 + p->n_solve_sync + sf_chol_plan::SOLVE_TICKETS * nst) * sizeof(int), st));
-    for (size_t k = 0; k < nst && !rc; ++k) {
+    for (size_t k = 0; k < nst; ++k) {
         const auto& s = p->solve_steps[k];
-        for (int q = 0; q < s.red_count && !rc; ++q) {
+        if (!rc && k > 0 && injected(p->rank, 4)) rc = SF_ERR_HIP;
+        for (int q = 0; q < s.red_count; ++q) {
             const auto& R = p->solve_reduces[(size_t)s.red_first + q];
             sf_comm* gc = group_comm(comm, R.mask);
-            rc = gc ? sf_comm_allreduce_sum(gc, (void*)(p->d_x + R.off), R.cnt, (void*)st) : SF_ERR_ARG;
+            if (!gc) { if (!rc) rc = SF_ERR_ARG; continue; }
+            // after a failure: emulated ranks keep the hand-shake of every remaining sum going (their peers wait on the host);
+            // RCCL peers are released by aborting the communicator below
+            if (rc) { if (gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, (void*)st); continue; }
+            rc = sf_comm_allreduce_sum(gc, (void*)(p->d_x + R.off), R.cnt, (void*)st);
         }
-        if (rc) break;
-        sf_solve_step_fwd(p, k, fwd_base, sync, tickets, st);
+        if (!rc) sf_solve_step_fwd(p, k, fwd_base, sync, tickets, st);
     }
+    if (rc) abort_comm(comm);
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
     sf::launch_solve_transpose_diag(p->d_solve, p->d_solveT_list, p->n_solveT, bwd_base, p->d_solveT, st);      // see sf_chol_plan_solve
     for (size_t k = nst; k-- > 0;) sf_solve_step_bwd(p, k, bwd_base, sync, tickets, st);
@@ -437,8 +502,18 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
     int rc = SF_OK;
     // the groups of a proportionally mapped plan: their sub-communicators are made once, by all ranks together
     if ((rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size()))) return rc;
-    if (host_out && (rc = sf_dl_begin(p, host_out))) return rc;
-    rc = sf_chol_plan_factorize_phase(p, 0, 0);
+    bool dl = false;
+    if (host_out) { rc = sf_dl_begin(p, host_out); dl = rc == SF_OK; }
+    if (!rc) rc = sf_chol_plan_factorize_phase(p, 0, 0);
+    if (!rc && injected(p->rank, 1)) rc = SF_ERR_HIP;
+    // The ranks agree on their state before the first data collective (one 8-byte sum on the second stream, which has nothing in
+    // front of it: the own subtrees enqueued above keep running meanwhile).  A rank whose copy workers or phase 0 could not be
+    // set up stops HERE, and so do its peers -- instead of enqueueing all-reduces that would wait for it on the GPU for ever.
+    if ((rc = agree_status(p, comm, rc, (hipStream_t)sf_plan_stream2(p)))) {
+        if (dl) (void)sf_dl_end(p);
+        (void)sf_chol_plan_sync(p);
+        return rc;
+    }
     const sf_long nseg = sf_chol_plan_num_segments(p);
     // Software pipeline over the segments: a segment's sum is issued on the plan's SECOND stream -- for a look-ahead segment
     // (Segment::early) one segment ahead of its use, so the collective of block J+1 travels while the chain of block J runs on the
@@ -458,6 +533,7 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
         return r ? r : sf_seg_reduced(p, k);
     };
     for (sf_long k = 0; k < nseg; ++k) {
+        if (!rc && k == nseg / 2 && injected(p->rank, 2)) rc = SF_ERR_HIP;
         if (rc) {
             if (!begun[k]) {
                 sf_comm* gc = group_comm(comm, p->segments[k].mask);
@@ -472,12 +548,24 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
     }
     int rc_dl = SF_OK;
     if (host_out) rc_dl = sf_dl_end(p);         // (also releases the copy workers when rc != 0)
-    if (rc) return rc;
+    if (rc) {
+        // in the middle of the segments: emulated peers were kept going by the hand-shakes above; RCCL peers may sit in a collective
+        // this rank never joined -- abort the communicator so that they (and every later call here) fail instead of hanging
+        abort_comm(comm);
+        (void)sf_chol_plan_sync(p);
+        return rc;
+    }
     if (sync || host_out) {
         const int rs = sf_chol_plan_sync(p);
         return rs ? rs : rc_dl;
     }
     return SF_OK;
+}
+
+// test hook: the next distributed factorization (where 1, 2) / solve (3, 4) fails on `rank` at that point, once
+void sf_test_inject_failure(int rank, int where) {
+    g_fail_rank.store(rank);
+    g_fail_where.store(where);
 }
 
 }  // extern "C"

@@ -140,7 +140,9 @@ struct sf_chol_plan {
     std::atomic<size_t> dl_next_piece{0};
     double* dl_host = nullptr;                  // destination of the running download (reference layout)
     // LU pivoting (sf_kernels.h, PivotCtl): threshold inside the 64 x 64 diagonal blocks, perturbation = piv_perturb * max|a_ij|
-    double piv_tol = 0.1, piv_perturb = 1.4901161193847656e-08 /* sqrt(eps) */, amax = 0;
+    // Defaults = the reference's behaviour: no pivoting, no perturbation (magma_dgetrf_nopiv, L:2653); opt-in by sf_lu_plan_set_pivoting,
+    // SparseFrame_set_pivoting (struct path) or SF_LU_PIVOT_TOL / SF_LU_PERTURB at plan creation
+    double piv_tol = 0.0, piv_perturb = 0.0, amax = 0;
     int32_t* d_piv = nullptr;   // pivpos[n] | pivinv[n] | perturbation counter
     int last_perturbed = 0;
     bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
@@ -161,6 +163,7 @@ struct sf_chol_plan {
     int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
     std::vector<Segment> segments;
     std::vector<uint32_t> all_masks;    // every group of the factorization (all ranks build the same sorted list)
+    double* d_status = nullptr;    // one word: the ranks' status agreement before the first data collective (sf_multi.hip)
     double* d_scratch = nullptr;   // packed segment buffers (2 x max over the segments: segment k uses half k & 1)
     int64_t scratch_elems = 0;
     bool lookahead = true;         // shared top panels: outer GEMM split into a far part (ahead of the previous chain) and the last block's
@@ -217,6 +220,8 @@ struct sf_chol_plan {
     int* d_flags = nullptr;     // k_step: one flag per (panel, fused step); == epoch once its diagonal block is factored
     double* d_tinv = nullptr;   // k_step: inverses of the 16 x 16 diagonal sub-blocks, per diagonal task of the running launch
     int epoch = 0;
+    std::vector<uint64_t> h_hash;    // per-supernode fingerprints of the factor of epoch hash_epoch (sf_plan_panel_hashes)
+    int hash_epoch = -1;
     GemmProb* d_probs = nullptr;
     GemmTask* d_gtasks = nullptr;
     GemmTask* d_stasks = nullptr;   // tiles of k_update_small
@@ -248,6 +253,9 @@ struct sf_chol_plan {
 // about to be enqueued with run_launches (which records and publishes the piece events while dl_active is set);
 // sf_dl_end publishes what is left, waits for the workers and returns SF_OK or the first error.
 int sf_dl_begin(sf_chol_plan* p, double* host_out);
+// per-supernode fingerprints (k_factor_hash) of the factor the plan holds, in the reference layout's index space; 0 for panels this
+// rank does not store.  Computed once per factorization (about one read of the factor), then cached.
+extern "C" int sf_plan_panel_hashes(sf_chol_plan* p, const uint64_t** out);
 int sf_dl_end(sf_chol_plan* p);
 // gathers the panels of the parts (plans of several ranks, one pattern) into the whole plan dst (sf_chol_plan.hip)
 int sf_plan_import_from(sf_chol_plan* dst, sf_chol_plan* const* parts, int nparts);

@@ -17,6 +17,18 @@ TOL_FACTOR = 1e-12
 TOL_RESIDUAL = 1e-13
 
 
+EXPERIMENT_KNOBS = ("SF_DL_2D", "SF_DL_LU_PACK", "SF_GEMM_DMA", "SF_GEMM_DYNAMIC", "SF_SOLVE_BWD_AHEAD", "SF_SOLVE_BWD_FUSED",
+                    "SF_SOLVE_DIAGT", "SF_SOLVE_FAR_GROUPS", "SF_SOLVE_FAR_WGS", "SF_SOLVE_FWD_AHEAD", "SF_SOLVE_FWD_FAR_FIRST",
+                    "SF_SU_MAXK", "SF_WEIGHTED_SHARES", "SF_DL_HOST_WAIT", "SF_DL_PIN", "SF_STREAM_PRIORITY")
+
+
+def needs_experiments(knobs):
+    """the A/B switches of finished experiments are compiled out of release builds (make EXP=1 keeps them): a case that sets one
+    is skipped unless the library has them -- setting it would silently test the default path a second time"""
+    if any(k in EXPERIMENT_KNOBS for k in knobs) and not sf.lib.sf_build_experiments():
+        pytest.skip("A/B switch compiled out of this build (make -C sparse-matrix-factorization-library_amd/csrc EXP=1)")
+
+
 def gpu_factor(sym):
     plan = sf.CholPlan(sym, device=0)
     plan.set_values(sym.Lx)
@@ -108,6 +120,7 @@ def test_struct_copy_back_knobs(oracle, monkeypatch, knobs):
     """every alternative of the overlapped copy-back (device-side event waits, 1 / 8 workers, 1 MiB slots so that this matrix has
     many pieces and 2-D pieces, 1-D copies only, ordinary streams, NUMA-confined workers): SparseFrame_factorize must leave the
     same Lsx -- every stored value, including the zero-filled rows above the block columns -- twice in a row"""
+    needs_experiments(knobs)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     N = 26
@@ -424,6 +437,7 @@ def test_device_solve_schedules(oracle, monkeypatch, knobs, method):
     """the solve's schedule variants (look-ahead of the far row tiles, multi-group far tasks, list order, row-major diagonal
     copies, two-launch backward steps) against the reference's host loops (oracle restatement); the matrix has supernodes of
     several 256-column steps, so every variant has something to do"""
+    needs_experiments(knobs)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     N = 34
@@ -572,6 +586,8 @@ def test_gemm_register_staged_form(oracle, monkeypatch):
     ref, info, _ = oracle.chol_factorize(sym)
     mask = oracle.lower_mask(sym)
     for dma in ("1", "0"):
+        if dma == "0" and not sf.lib.sf_build_experiments():
+            continue                        # the register-staged form is compiled out of release builds (make EXP=1)
         monkeypatch.setenv("SF_GEMM_DMA", dma)
         plan, Lsx = gpu_factor(sym)
         plan.close()
@@ -691,8 +707,32 @@ def test_struct_solve_runs_on_the_resident_factor(oracle, monkeypatch):
     x_host = mi.array("Xx", n).copy()
     assert np.max(np.abs(x_dev - x_host)) <= 1e-12 * np.max(np.abs(x_host))
     monkeypatch.delenv("SF_SOLVE")
-    # the caller scales its host copy: the sample no longer matches, the solve follows the HOST data (x scales by 1/4)
+    # the caller changes ONE value of its host copy, anywhere (here: the last bit of a diagonal entry of a mid-size panel, far from
+    # the three windows the round-2 check sampled): every panel's fingerprint is compared, the solve follows the HOST data
     Lsx = mi.array("Lsx", int(mi.c.xsize))
+    s_mid = int(np.argmin(np.abs(np.asarray(mi.array("Lsxp", int(mi.c.nsuper) + 1)) - int(mi.c.xsize) // 3)))
+    at = int(mi.array("Lsxp", int(mi.c.nsuper) + 1)[s_mid])
+    keep = float(Lsx[at])
+    Lsx[at] = np.nextafter(keep, 2 * keep)
+    mi.validate()
+    assert lib.sf_handlers_resident_solves() == before + 1            # host fallback
+    Lsx[at] = keep
+    mi.factorize(common)                                               # resident again
+    # trusted mode: the caller vouches for Lsx, nothing is compared -- the device's factor answers even though the host copy differs
+    assert lib.sf_handlers_set_resident_solve(2) == 0
+    Lsx[at] = 3.0 * keep
+    mi.validate()
+    assert lib.sf_handlers_resident_solves() == before + 2
+    assert np.max(np.abs(mi.array("Xx", n) - x_host)) <= 1e-12 * np.max(np.abs(x_host))
+    Lsx[at] = keep
+    assert lib.sf_handlers_set_resident_solve(0) == 0                  # never: always the reference's host sweep
+    mi.validate()
+    assert lib.sf_handlers_resident_solves() == before + 2
+    assert lib.sf_handlers_set_resident_solve(1) == 0 and lib.sf_handlers_set_resident_solve(7) != 0
+    mi.validate()
+    assert lib.sf_handlers_resident_solves() == before + 3            # verified mode, unmodified copy: resident
+    before += 2
+    # the caller scales its host copy: the solve follows the HOST data (x scales by 1/4)
     Lsx *= 2.0
     mi.validate()
     assert lib.sf_handlers_resident_solves() == before + 1

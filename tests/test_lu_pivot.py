@@ -4,14 +4,31 @@ parity with: PARITY UNPINNED by construction.  Acceptance, as for any pivoted sp
   * on diagonally dominant inputs the pivoted factorization takes exactly the no-pivot path's pivots (they pass the threshold)
     -- and that one is in parity with the oracle (tests/test_lu.py);
   * on inputs that break the no-pivot path (exact zero pivots) or make it inaccurate (non-dominant), the scaled residual of the
-    solve with the recorded interchanges is <= 1e-10 (device solve and the struct library's host solve)."""
+    solve with the recorded interchanges is <= 1e-10 (device solve and the struct library's host solve);
+  * round 3: the rule itself (threshold test, tie rule, perturbation, what moves with a row) is restated in scalar C in the oracle
+    (sfo_lu_factorize_pivot; pinned on the CPU in tests/test_lu_pivot_oracle.py against LAPACK partial pivoting and a numpy
+    statement of the block-restricted rule): the HIP path's pivot sequence and PivInv must EQUAL the oracle's and its L / U
+    values agree to 1e-12 of the largest entry (1e-10 on the non-dominant random matrices, whose element growth under
+    block-restricted pivoting amplifies the rounding differences of two summation orders), also against committed vectors
+    (tests/golden/lu_small.json)."""
+import json
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from util import sf, gen, nd_perm_py
+from util import sf, gen, nd_perm_py, rel_err
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def struct_pivoting():
+    """opt in to pivoting on the struct path (process-wide policy), and back to the reference's behaviour afterwards"""
+    sf.LUMatrixInfo.set_pivoting(0.1, 1.4901161193847656e-08)
+    yield
+    sf.LUMatrixInfo.set_pivoting(0.0, 0.0)
 
 
 def permuted_matrix(S):
@@ -104,7 +121,7 @@ def test_non_dominant_random_matrix_residual():
     plan.close()
 
 
-def test_struct_entry_points_with_interchanges():
+def test_struct_entry_points_with_interchanges(struct_pivoting):
     """LU library: SparseFrame_factorize records the interchanges in matrix_info->PivInv, SparseFrame_solve_supernodal
     (host) applies them block by block; validate()'s residual is the reference's formula"""
     N = 10
@@ -130,7 +147,7 @@ def test_struct_entry_points_with_interchanges():
     common.close()
 
 
-def test_interchanges_in_shared_top_panels_emulated_ranks(monkeypatch):
+def test_interchanges_in_shared_top_panels_emulated_ranks(monkeypatch, struct_pivoting):
     """two emulated handlers: exact zeros on the diagonal inside the TOP supernodes, whose 64-column chains run replicated
     on both ranks after the all-reduce -- both must take the same pivots (their inputs are bit-identical), the factor pieces
     come back from different ranks, PivInv is assembled from both, and the host solve must still reproduce b"""
@@ -163,5 +180,200 @@ def test_interchanges_in_shared_top_panels_emulated_ranks(monkeypatch):
     piv = mi.array("PivInv", n)
     assert sorted(piv.tolist()) == list(range(n)) and np.count_nonzero(piv != np.arange(n)) >= 2
     assert mi.validate() <= 1e-10
+    mi.cleanup()
+    common.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: the HIP path against the oracle's statement of the pivoting rule
+# ---------------------------------------------------------------------------------------------------------------------
+def _dense_csc(A):
+    n = A.shape[0]
+    return n, np.arange(0, n * n + 1, n, dtype=np.int64), np.tile(np.arange(n, dtype=np.int64), n), np.ascontiguousarray(A.T).ravel()
+
+
+def _zeroed_diagonal_case(N, seed, every):
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=seed)
+    perm = nd_perm_py(N, N, N)
+    S0 = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    Cx = Cx.copy()
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    for j in range(0, n, every):
+        g = S0.Perm[j]
+        Cx[(Ci == g) & (cols == g)] = 0.0
+    return n, Cp, Ci, Cx, perm
+
+
+def pivot_cases():
+    c = []
+    rng = np.random.default_rng(11)
+    c.append(("dense_64_tol1", *_dense_csc(rng.uniform(-1, 1, (64, 64))), None, 1.0, 1e-12))
+    c.append(("dense_200_tol01", *_dense_csc(rng.uniform(-1, 1, (200, 200))), None, 0.1, 1e-10))
+    c.append(("dense_700_tol05", *_dense_csc(rng.uniform(-1, 1, (700, 700)) + 4 * np.eye(700)), None, 0.5, 1e-11))
+    c.append(("zero_diag_12", *_zeroed_diagonal_case(12, 9, 7), 0.1, 1e-12))
+    c.append(("zero_diag_16", *_zeroed_diagonal_case(16, 10, 5), 0.3, 1e-11))      # multipliers of 1e6 next to the zeroed entries
+    n, Cp, Ci, Cx = gen.unsymmetric_general(10, 10, 10, seed=21)
+    c.append(("general_10_tol1", n, Cp, Ci, Cx, nd_perm_py(10, 10, 10), 1.0, 1e-10))
+    n, Cp, Ci, Cx = gen.unsymmetric_general(14, 14, 14, seed=22, diag_scale=1.0)
+    c.append(("general_14_tol03", n, Cp, Ci, Cx, nd_perm_py(14, 14, 14), 0.3, 1e-10))
+    return c
+
+
+@pytest.mark.parametrize("fuse", ["", "0"], ids=["fused_step", "three_launches"])
+@pytest.mark.parametrize("case", pivot_cases(), ids=lambda c: c[0])
+def test_pivot_sequence_and_factor_match_the_oracle(oracle, monkeypatch, case, fuse):
+    name, n, Cp, Ci, Cx, perm, tol, vtol = case
+    if fuse:
+        monkeypatch.setenv("SF_FUSE_MAX", fuse)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    ref, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=tol)
+    assert info == 0
+    plan = sf.LUPlan(S)
+    plan.set_values(S.Lx, S.Ux)
+    plan.set_pivoting(tol)
+    plan.factorize()
+    got_piv = plan.get_pivots()
+    assert np.array_equal(got_piv, pivpos), (name, np.flatnonzero(got_piv != pivpos)[:10])
+    assert np.count_nonzero(pivpos != np.arange(n)) > 0
+    assert int(plan.stat("perturbed_pivots")) == nper
+    Lsx = plan.get_factor()
+    assert rel_err(Lsx, ref) <= vtol, (name, rel_err(Lsx, ref))
+    # the device solve (interchanges applied block by block in the forward sweep) against the oracle's solve with ITS factor
+    b = 1.0 + np.arange(n) / n
+    x = plan.solve(b)
+    want = oracle.lu_solve_pivot(S, ref, pivpos, b)
+    # (zero_diag_16: pivots of 1e-6 next to the zeroed entries make the SOLUTION sensitive to the last bits of the factor -- 1e6 x the
+    # factor's 1e-12; the factor itself and the pivot sequence are compared above)
+    xtol = 1e-6 if name == "zero_diag_16" else max(vtol, 1e-11) * 1e2
+    assert np.max(np.abs(x - want)) <= xtol * np.abs(want).max(), name
+    plan.close()
+
+
+def test_perturbed_pivots_match_the_oracle(oracle):
+    """a column that is zero in its whole diagonal block: both sides replace the pivot by +sqrt(eps) max|a_ij| and count it"""
+    n = 40
+    rng = np.random.default_rng(3)
+    A = rng.uniform(-1, 1, (n, n))
+    A[:, 7] = 0.0
+    A[:, 23] = 0.0
+    A[5, 7] = 1e-30          # below the perturbation threshold, not zero: sign kept
+    S = sf.analyze(*_dense_csc(A), None, 1 << 30, "lu", False)
+    ref, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=1.0)
+    assert nper == 2 and info == 0
+    plan = sf.LUPlan(S)
+    plan.set_values(S.Lx, S.Ux)
+    plan.set_pivoting(1.0)
+    plan.factorize()
+    assert int(plan.stat("perturbed_pivots")) == 2
+    assert np.array_equal(plan.get_pivots(), pivpos)
+    assert rel_err(plan.get_factor(), ref) <= 1e-9      # 1 / sqrt(eps) multipliers
+    plan.close()
+
+
+def test_lu_golden_fixtures():
+    """committed vectors (tests/golden/make_golden_lu.py: oracle output accepted there only after agreeing with dense no-pivot
+    LU / LAPACK partial pivoting / the numpy block rule / a solve); no oracle code runs here"""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lu_small.json")) as f:
+        G = json.load(f)
+    assert any(k.startswith("piv_") for k in G) and any(k.startswith("nopiv_") for k in G)
+    for name, g in G.items():
+        S = sf.analyze(g["n"], g["Cp"], g["Ci"], g["Cx"], g["perm"], g["devSlotSize"], "lu", g["symmetric"])
+        for k in ("Super", "Lsip", "Lsxp", "Lsi", "Perm"):
+            assert np.array_equal(getattr(S, k), np.asarray(g[k], dtype=np.int64)), (name, k)
+        plan = sf.LUPlan(S)
+        plan.set_values(S.Lx, None if g["symmetric"] else S.Ux)
+        plan.set_pivoting(g["tol"], g["perturb"])
+        plan.factorize()
+        if g["pivpos"] is not None:
+            assert np.array_equal(plan.get_pivots(), np.asarray(g["pivpos"])), name
+        else:
+            assert np.array_equal(plan.get_pivots(), np.arange(g["n"])), name
+        assert int(plan.stat("perturbed_pivots")) == g["perturbed"]
+        assert rel_err(plan.get_factor(), np.asarray(g["Lsx"])) <= (1e-10 if name.startswith("piv_general") else 1e-12), name
+        plan.close()
+
+
+@pytest.mark.parametrize("handlers", [1, 2])
+def test_struct_path_pivinv_and_factor_match_the_oracle(oracle, monkeypatch, handlers, struct_pivoting):
+    """SparseFrame_factorize (LU library): matrix_info->PivInv and every value of matrix_info->Lsx against the oracle, with
+    one handler and with two emulated handlers whose SHARED top panels carry zeroed diagonal entries (both ranks must take the
+    oracle's pivots; the pieces of Lsx come back from different ranks)"""
+    if handlers > 1:
+        if sf.device_count() != 1:
+            pytest.skip("emulated handlers are for one-GPU boxes")
+        monkeypatch.setenv("SF_EMULATE_HANDLERS", str(handlers))
+    N = 12
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=31)
+    perm = nd_perm_py(N, N, N)
+    S0 = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    owner, _, _ = sf.subtree_partition(S0, 2, 0.75)
+    Cx = Cx.copy()
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    for s in [s for s in range(S0.nsuper) if owner[s] < 0]:
+        for j in range(S0.Super[s], S0.Super[s + 1], 37):
+            g = S0.Perm[j]
+            Cx[(Ci == g) & (cols == g)] = 0.0
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    ref, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=0.1)
+    assert info == 0 and np.count_nonzero(pivpos != np.arange(n)) >= 2
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    assert common.c.numGPU == handlers
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    mi.factorize(common)
+    assert np.array_equal(mi.array("PivInv", n), pivpos)        # (the field holds original row -> position, see sparseframe_lu_hip.h)
+    assert mi.perturbed_pivots() == 0 and nper == 0
+    Lsx = mi.array("Lsx", int(S.xsize))
+    assert rel_err(Lsx, ref) <= 1e-12
+    assert mi.validate() <= 1e-10
+    mi.cleanup()
+    common.close()
+
+
+def test_struct_path_default_is_the_reference_no_pivot_behaviour(oracle):
+    """without SparseFrame_set_pivoting the LU library factors as the reference does: PivInv = identity, Lsx = the no-pivot
+    oracle's, and an exact zero pivot is reported instead of being worked around"""
+    N = 10
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=4)
+    perm = nd_perm_py(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    ref, info, _ = oracle.lu_factorize(S)
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    mi.factorize(common)
+    assert np.array_equal(mi.array("PivInv", n), np.arange(n)) and mi.perturbed_pivots() == 0
+    assert rel_err(mi.array("Lsx", int(S.xsize)), ref) <= 1e-12
+    mi.cleanup()
+    Cx = Cx.copy()
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    g = S.Perm[S.Super[0]]
+    Cx[(Ci == g) & (cols == g)] = 0.0
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_NOT_POSDEF"):
+        mi.factorize(common)
+    mi.cleanup()
+    common.close()
+
+
+def test_reanalysis_of_a_larger_matrix_resizes_pivinv(struct_pivoting):
+    """PivInv was allocated once per matrix_info; a re-analysis with a larger matrix overflowed it"""
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    mi = sf.LUMatrixInfo()
+    for N in (4, 9):
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=N)
+        mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+        mi.set_perm(nd_perm_py(N, N, N))
+        mi.analyze(common)
+        mi.factorize(common)
+        assert np.array_equal(mi.array("PivInv", n), np.arange(n))
+        assert mi.validate() <= 1e-13
     mi.cleanup()
     common.close()

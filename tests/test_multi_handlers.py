@@ -35,8 +35,7 @@ def _chol_case(oracle, N, nhandlers_expected):
         mi.analyze(common)
         C.memset(mi.c.Lsx, 0xff, 8 * sym.xsize)          # NaNs: every entry must be written by some rank's copy-back
         mi.factorize(common)
-        if os.environ.get("SF_GEMM_WHOLE_TILES") != "0":          # (the A/B knob that switches the property off)
-            assert sf._lib.lib.sf_handlers_replica_mismatches(mi.c.Lsx) == 0      # shared panels: bit-identical on the ranks of a group
+        assert sf._lib.lib.sf_handlers_replica_mismatches(mi.c.Lsx) == 0          # shared panels: bit-identical on the ranks of a group
         got = mi.array("Lsx", sym.xsize).copy()
         assert not np.isnan(got[mask]).any()
         assert rel_err(got, ref * np.sqrt(scale), mask) <= TOL_FACTOR
@@ -166,6 +165,14 @@ def test_distributed_solve_with_the_factor_left_on_the_ranks(monkeypatch, method
     assert mi.validate() <= TOL_RESIDUAL
     x_host = mi.array("Xx", n).copy()
     assert np.max(np.abs(x_dist - x_host)) <= 1e-12 * np.max(np.abs(x_host))
+    # one changed value in the caller's copy (the root panel's last entry): every panel's fingerprint is compared with every rank
+    # that stores it, so the ranks are NOT asked and the host sweep answers for the data the caller holds
+    monkeypatch.delenv("SF_SOLVE")
+    Lsx = mi.array("Lsx", int(mi.c.xsize))
+    Lsx[-1] *= 1.0 + 1e-9
+    k = lib.sf_handlers_resident_solves()
+    mi.validate()
+    assert lib.sf_handlers_resident_solves() == k
     mi.cleanup()
     common.close()
 
@@ -187,8 +194,7 @@ def test_lookahead_schedule_lu(oracle, monkeypatch):
     mi.set_perm(perm)
     mi.analyze(common)
     mi.factorize(common)
-    if os.environ.get("SF_GEMM_WHOLE_TILES") != "0":
-        assert sf._lib.lib.sf_handlers_replica_mismatches(mi.c.Lsx) == 0
+    assert sf._lib.lib.sf_handlers_replica_mismatches(mi.c.Lsx) == 0
     assert mi.validate() <= TOL_RESIDUAL
     S = sf.analyze(n, Cp, Ci, Cx, perm, 8 << 30, "lu", False)
     assert np.diff(S.Super).max() > 1024
@@ -309,4 +315,86 @@ def test_one_handler_list_two_patterns_emulated(oracle, monkeypatch):
         mi.factorize(common)
         assert rel_err(mi.array("Lsx", sym.xsize).copy(), ref, oracle.lower_mask(sym)) <= TOL_FACTOR
         mi.cleanup()
+    common.close()
+
+
+@pytest.mark.parametrize("where", [1, 2, 3, 4])
+@pytest.mark.parametrize("method", ["cholesky", "lu"])
+def test_a_failing_rank_does_not_leave_its_peers_waiting(monkeypatch, method, where):
+    """a rank that fails before its first collective (where = 1 factorization, 3 solve) or in the middle of a run (2, 4)
+    used to return alone -- its peers then waited for ever (in LocalGroup::barrier here, in an RCCL kernel on real ranks).  Now the
+    ranks agree on their state before the first data collective and keep the hand-shake going after a mid-run failure: every
+    handler thread returns, the call reports an error, and the NEXT factorization / solve on the same handlers works."""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    import threading
+    lib = sf._lib.lib
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", "3")
+    N = 20
+    if method == "lu":
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=3)
+        mi = sf.LUMatrixInfo()
+        kw = dict(symmetric=False)
+    else:
+        n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+        mi = sf.MatrixInfo()
+        kw = {}
+    common = sf.CommonInfo(dev_slot_size=8 << 30)
+    mi.set_csc(n, Cp, Ci, Cx, **kw)
+    mi.set_perm(nd_perm_py(N, N, N))
+    mi.analyze(common)
+    mi.factorize(common)                                   # builds plans and communicators
+    assert mi.validate() <= TOL_RESIDUAL
+    result = {}
+
+    def run():
+        try:
+            if where <= 2:
+                mi.factorize(common)
+                result["rc"] = "ok"
+            else:
+                result["res"] = mi.validate()          # solve: a failed distributed solve falls back to the host sweep
+                result["rc"] = "ok"
+        except sf.SparseFrameError as e:
+            result["rc"] = str(e)
+
+    lib.sf_test_inject_failure(1, where)
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "a handler thread is still waiting for the failed rank"
+    if where <= 2:
+        assert "SF_ERR" in result["rc"], result
+    else:
+        assert result["rc"] == "ok" and result["res"] <= TOL_RESIDUAL       # answered by the host solve
+    lib.sf_test_inject_failure(-1, 0)
+    mi.factorize(common)                                   # the handlers are still usable
+    assert mi.validate() <= TOL_RESIDUAL
+    mi.cleanup()
+    common.close()
+
+
+def test_three_launch_chain_steps_keep_replicas_identical(oracle, monkeypatch):
+    """with SF_FUSE_MAX=0 the 64-column steps of a SHARED panel run as three launches whose K = 64 t GEMM used to split
+    tiles by K (several atomic additions per element, in a rank-dependent order): replicas could differ in the last bits, and an LU
+    threshold-pivot decision with them.  The launch now runs whole tiles for shared sets."""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", "2")
+    monkeypatch.setenv("SF_FUSE_MAX", "0")
+    N = 24
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=13)
+    perm = nd_perm_py(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 8 << 30, "lu", False)
+    ref, info, _ = oracle.lu_factorize(S)
+    common = sf.CommonInfo(dev_slot_size=8 << 30)
+    mi = sf.LUMatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    mi.factorize(common)
+    assert sf._lib.lib.sf_handlers_replica_mismatches(mi.c.Lsx) == 0
+    assert rel_err(mi.array("Lsx", S.xsize).copy(), ref) <= TOL_FACTOR
+    assert mi.validate() <= TOL_RESIDUAL
+    mi.cleanup()
     common.close()
