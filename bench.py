@@ -92,7 +92,9 @@ def hbm_roofline_whole_factorization(plan, sym, ms):
 def secondary_case(sf, np, kind, steps=3):
     """one more BASELINE config timed in the same run (driver-side numbers for configs 3 and 5):
     kind 'config3' = 2-D 1000x1000 21-point random SPD stencil (the HBM-/latency-bound extend-add config),
-    kind 'config5' = unsymmetric 19-point stencil 79^3, LU with threshold pivoting inside the diagonal blocks."""
+    kind 'config5' = unsymmetric 19-point stencil 79^3, LU with threshold pivoting inside the diagonal blocks (diagonally dominant:
+    the natural pivots pass), kind 'config5_pivoting' = the same matrix with a fifth of its diagonal weakened so that rows really
+    are interchanged."""
     t0 = time.time()
     if kind == "config3":
         M = 1000
@@ -104,13 +106,19 @@ def secondary_case(sf, np, kind, steps=3):
     else:
         M = 79
         n, Cp, Ci, Cx = sf.gen.unsymmetric_stencil(M, M, M, extra_per_row=0, seed=2024, drop=0.05)
+        weak = kind == "config5_pivoting"
+        if weak:
+            n, Cp, Ci, Cx = sf.gen.weaken_diagonal(n, Cp, Ci, Cx, fraction=0.2, factor=0.02, seed=77)
         sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(M, M, M, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False)
         plan = sf.LUPlan(sym)
         plan.set_values(sym.Lx, sym.Ux)
         plan.set_pivoting(0.1)
         wl = ("unsymmetric 3D 19-point stencil 79^3 (5% of the entries dropped one-sidedly; SURVEY 8d's one random long-range entry "
-              "per row is not used: it destroys the grid separators and the fill explodes under a geometric ordering), diagonally "
-              "dominant, LU fp64 with threshold partial pivoting (tol 0.1) inside the 64x64 diagonal blocks")
+              "per row is not used: the factor of that matrix is ~0.6 n^2 doubles under any ordering (profiles/r03_config5_rescope.txt: "
+              "26x the stand-in's at 30^3, 1.2 TB at n = 493k)), "
+              + ("20% of the diagonal entries multiplied by 0.02 (those rows are NOT diagonally dominant: the threshold test fails "
+                 "there and rows are interchanged)" if weak else "diagonally dominant (every natural pivot passes the threshold)")
+              + ", LU fp64 with threshold partial pivoting (tol 0.1) inside the 64x64 diagonal blocks")
     t_setup = time.time() - t0
     plan.factorize()
     t0 = time.perf_counter()
@@ -151,6 +159,16 @@ def secondary_case(sf, np, kind, steps=3):
         np.add.at(colsum, sym.Ui[off], np.abs(sym.Ux[off]))
         out["residual_host_check"] = float(np.abs(r).max() / (colsum.max() * np.abs(x).max() + np.abs(r * 0 + 1 + np.arange(n) / n).max()))
         out["residual_device_solve"] = plan.validate()          # solve + residual on the device
+        if kind == "config5_pivoting":
+            # two steps of iterative refinement on the host residual (what a perturbed or growth-affected factor calls for)
+            import scipy.sparse as sp
+            A = (sp.coo_matrix((sym.Lx, (sym.Li, lc)), shape=(n, n)) + sp.coo_matrix((sym.Ux[off], (ur[off], sym.Ui[off])), shape=(n, n))).tocsr()
+            bvec = 1 + np.arange(n) / n
+            xr = x
+            for _ in range(2):
+                xr = xr + plan.solve(bvec - A @ xr)
+            rr = A @ xr - bvec
+            out["residual_after_2_refinements"] = float(np.abs(rr).max() / (colsum.max() * np.abs(xr).max() + np.abs(bvec).max()))
     plan.close()
     return out
 
@@ -492,9 +510,19 @@ def main():
             mi.factorize(common)
             st.append(mi.c.factorizeTime * 1e3)
         pc = {}
+        # the struct path's solve runs on the factor still resident in the handler's plan -- by default only after the fingerprint of
+        # EVERY panel of the caller's Lsx has been compared with the device's (one threaded pass over the host array: that pass is
+        # most of struct_solve_ms); sf_handlers_set_resident_solve(2) = the caller vouches for Lsx, nothing is compared
+        res_struct = mi.validate()
+        solve_verified_ms = 1e3 * mi.c.solveTime
+        sf.lib.sf_handlers_set_resident_solve(2)
+        mi.validate()
+        solve_trusted_ms = 1e3 * mi.c.solveTime
+        sf.lib.sf_handlers_set_resident_solve(1)
         pc.update({"struct_first_call_ms": round(st[0], 1), "struct_second_call_ms": round(st[1], 1),
                    "struct_second_call_over_resident_step": round(st[1] / ms_per_step, 3),
-                   "struct_residual": mi.validate(), "struct_solve_ms": round(1e3 * mi.c.solveTime, 3),      # the solve finds the factor resident in the handler's plan
+                   "struct_residual": res_struct, "struct_solve_ms": round(solve_verified_ms, 3),
+                   "struct_solve_trusted_ms": round(solve_trusted_ms, 3),
                    "note": "SparseFrame_factorize(common, gpu_info_list, matrix_info): pageable Lsx malloc'ed by SparseFrame_analyze; "
                            "call 1 = plan build + first touch of Lsx + factorize + overlapped copy-back, call 2 = cached plan"})
         mi.cleanup()
@@ -527,7 +555,8 @@ def main():
 
     if rank == 0 and ngpu == 1 and not args.no_secondary and not lu and args.workload == "lap3d" and args.grid in (0, 128):
         out["secondary"] = {"config1": config1_case(sf, np), "config3": secondary_case(sf, np, "config3"),
-                            "config5": secondary_case(sf, np, "config5")}
+                            "config5": secondary_case(sf, np, "config5"),
+                            "config5_pivoting": secondary_case(sf, np, "config5_pivoting")}
 
     if args.cpu_grid < 0:
         args.cpu_grid = min(N, 128)

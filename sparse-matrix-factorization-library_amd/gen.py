@@ -177,6 +177,19 @@ def unsymmetric_general(nx, ny=1, nz=1, seed=7, reach=1, diag_scale=0.3):
     return n, Cp, Ci, Cx
 
 
+def weaken_diagonal(n, Cp, Ci, Cx, fraction=0.2, factor=0.02, seed=77):
+    """a copy of the whole-matrix CSC (n, Cp, Ci, Cx) in which a random `fraction` of the diagonal entries is multiplied by
+    `factor`: those rows lose their diagonal dominance, a threshold-pivoting LU has to interchange rows there (BASELINE config 5
+    'with partial pivoting' exercised for real; the matrix stays far from singular: the other entries are untouched)"""
+    rng = np.random.default_rng(seed)
+    Cx = np.array(Cx, dtype=np.float64, copy=True)
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    dpos = np.flatnonzero(np.asarray(Ci) == cols)
+    pick = dpos[rng.random(dpos.size) < fraction]
+    Cx[pick] *= factor
+    return n, Cp, Ci, Cx
+
+
 def dense_from_csc(n, Cp, Ci, Cx):
     A = np.zeros((n, n))
     for j in range(n):

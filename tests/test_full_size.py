@@ -80,6 +80,7 @@ def test_config5_unsymmetric_lu_79cubed_properties():
     sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False)
     plan = sf.LUPlan(sym)
     plan.set_values(sym.Lx, sym.Ux)
+    plan.set_pivoting(0.1)
     plan.factorize()
     assert plan.validate() <= 1e-13
     assert np.array_equal(plan.get_pivots(), np.arange(n))          # diagonally dominant: the natural pivots pass the threshold
@@ -92,4 +93,38 @@ def test_config5_unsymmetric_lu_79cubed_properties():
     b += np.bincount(ur[off], weights=sym.Ux[off], minlength=n)
     x = plan.solve(b)
     assert np.max(np.abs(x - 1.0)) <= 1e-10
+    plan.close()
+
+
+def test_config5_with_a_weakened_diagonal_really_interchanges_rows():
+    """BASELINE config 5 says 'with partial pivoting': on the diagonally dominant stand-in the pivoting code never moves a row, so
+    here a fifth of the diagonal entries is multiplied by 0.02 (those rows fail the threshold test).  PARITY UNPINNED (the reference
+    never pivots); accepted by size-independent properties: the pivot record is a permutation that stays inside the 64-column
+    blocks, rows really moved, the no-pivot path on the same matrix is worse or fails, and the known answer comes back after
+    iterative refinement."""
+    import scipy.sparse as sp
+    g = 79
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(g, g, g, extra_per_row=0, seed=2024, drop=0.05)
+    n, Cp, Ci, Cx = gen.weaken_diagonal(n, Cp, Ci, Cx, fraction=0.2, factor=0.02, seed=77)
+    sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False)
+    plan = sf.LUPlan(sym)
+    plan.set_values(sym.Lx, sym.Ux)
+    plan.set_pivoting(0.1)
+    plan.factorize()
+    piv = plan.get_pivots()
+    moved = int(np.count_nonzero(piv != np.arange(n)))
+    assert moved > 1000, moved
+    assert np.array_equal(np.sort(piv), np.arange(n))
+    sup = sym.SuperMap
+    assert np.array_equal(sup[piv], sup)
+    assert np.array_equal((piv - sym.Super[sup]) // 64, (np.arange(n) - sym.Super[sup]) // 64)
+    lc = np.repeat(np.arange(n), np.diff(sym.Lp))
+    ur = np.repeat(np.arange(n), np.diff(sym.Up))
+    off = sym.Ui != ur
+    A = (sp.coo_matrix((sym.Lx, (sym.Li, lc)), shape=(n, n)) + sp.coo_matrix((sym.Ux[off], (ur[off], sym.Ui[off])), shape=(n, n))).tocsr()
+    b = A @ np.ones(n)
+    x = plan.solve(b)
+    for _ in range(2):
+        x = x + plan.solve(b - A @ x)
+    assert np.max(np.abs(x - 1.0)) <= 1e-9, (np.max(np.abs(x - 1.0)), plan.stat("perturbed_pivots"))
     plan.close()
