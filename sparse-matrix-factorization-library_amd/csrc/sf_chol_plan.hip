@@ -194,6 +194,20 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     const bool trace_pc = getenv("SF_TRACE") != nullptr;
     auto pc_now = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec / 1e6; };
     const double pc_t0 = pc_now();
+    // The factor's allocation (tens of GB: tens of ms in the driver, more on a box's first large allocation) runs on a thread of its
+    // own while this one builds the task tables.  + 2 doubles: the GEMM stages row PAIRS with 16-byte loads and may touch 8 bytes
+    // past the last panel.
+    const size_t xb_factor = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double);
+    hipError_t factor_alloc_err = hipSuccess;
+    double* factor_mem = nullptr;           // handed to the plan once everything else has succeeded; freed by the guard otherwise
+    std::thread factor_alloc([&factor_alloc_err, &factor_mem, xb_factor, device] {
+        factor_alloc_err = hipSetDevice(device);
+        if (factor_alloc_err == hipSuccess) factor_alloc_err = hipMalloc((void**)&factor_mem, xb_factor);
+    });
+    struct JoinAlloc {
+        std::thread& t; double*& mem;
+        ~JoinAlloc() { if (t.joinable()) t.join(); if (mem) (void)hipFree(mem); }
+    } join_alloc{factor_alloc, factor_mem};
     // ---------------- validate the structure the kernels index with ----------------
     for (sf_long s = 0; s < nsuper; ++s) {
         const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
@@ -1095,9 +1109,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         for (Launch& L : p->launches)
             if (L.kind == 2 || L.kind == 3 || L.kind == 4) { L.ticket = p->n_tickets; p->n_tickets += 8; }
         if (const char* env = sf_exp_env("SF_GEMM_DYNAMIC")) p->gemm_dynamic = atoi(env) != 0;
-        // + 2 doubles: the GEMM stages row PAIRS with 16-byte loads and may touch 8 bytes past the last panel
-        const size_t xb = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double), vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
-        if (hipMalloc((void**)&p->d_Lsx, xb) != hipSuccess || hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
+        const size_t xb = xb_factor, vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
+        factor_alloc.join();
+        if (factor_alloc_err != hipSuccess) { (void)hipGetLastError(); rc = SF_ERR_ALLOC; break; }
+        p->d_Lsx = factor_mem;
+        factor_mem = nullptr;
+        if (hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
             hipMalloc((void**)&p->d_info, (1 + p->n_tickets) * sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
         p->bytes_device += xb + vb + (1 + p->n_tickets) * sizeof(int);
     } while (0);
@@ -1890,6 +1907,10 @@ int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     p->dl_t0 = dl_now();
     const int nw = (int)std::min<size_t>(p->dl_workers, p->dl_pieces.size());
     for (int w = 0; w < nw; ++w) p->dl_threads.emplace_back(dl_worker, p, w);
+    // (First touch of a just-malloc'ed destination is left to the copy workers.  Helper threads that populate the page tables ahead
+    // of them -- MADV_POPULATE_WRITE over the array in address order -- were measured and make the first call SLOWER: 637 ms of
+    // copy-back with none, 857 ms with 2, 1100 ms with 8 or 16 at 128^3 (profiles/r03_d_first_call_touch_threads.txt): the page
+    // allocator serialises them with the workers' own faults.)
     return SF_OK;
 }
 
