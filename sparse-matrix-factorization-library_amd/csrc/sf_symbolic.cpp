@@ -13,6 +13,7 @@
 // aliasing) but each pass is written to reproduce the reference's tie-breaking exactly.
 #include "sf_symbolic.h"
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <time.h>
 #include <cstdio>
@@ -39,7 +40,7 @@ int analysis_threads() {
     static const int T = [] {
         if (const char* e = getenv("SF_ANALYZE_THREADS")) return std::max(1, atoi(e));
         const unsigned hc = std::thread::hardware_concurrency();
-        return (int)std::min<unsigned>(hc ? hc : 1u, 8u);
+        return (int)std::min<unsigned>(hc ? hc : 1u, 16u);
     }();
     return T;
 }
@@ -737,11 +738,172 @@ void nd_bfs(NdCtx& c, Long id, Long root, std::vector<Long>& order) {
 }
 
 void nd_component(NdCtx& c, std::vector<Long>& comp, Long pos);
+void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team);
+
+// ---- big pieces: the BFS itself is shared by a TEAM of threads -------------------------------------------------------------------
+// At the top of the dissection there are 1, 2, 4, ... pieces: one thread per piece leaves the other threads idle exactly where the
+// pieces are largest (the whole graph is swept three times by one thread).  Pieces of at least ND_PAR_MIN vertices therefore run a
+// level-synchronous BFS in which the threads of a team split every frontier; a vertex is claimed with one compare-and-swap on its
+// mark.  WHICH thread claims a vertex is a race, so the order inside a level is not reproducible -- and nothing below uses it: the
+// level of every vertex, the level sets and the smallest vertex of the last level are the same for any team size, the restart root
+// is that smallest vertex, and the vertex lists handed down are kept sorted by vertex number (a filter of a sorted list).  A piece
+// takes this path or the sequential one by its SIZE alone, so the permutation does not depend on the number of threads.
+constexpr Long ND_PAR_MIN = 100000;
+
+struct SpinBarrier {
+    std::atomic<int> cnt{0}, gen{0};
+    int n = 1;
+    void wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (cnt.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { cnt.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); }
+        else while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+    }
+};
+
+// BFS of piece `id` from `root` by `team` threads.  order: the visited vertices, level by level (capacity `cap` >= piece size);
+// level[] filled; the marks of the visited vertices end as `final_mark`.  Returns the number of levels; *last_min = smallest vertex
+// of the last level.
+Long nd_bfs_team(NdCtx& c, Long id, Long root, int team, Long cap, Long final_mark, std::vector<Long>& order, Long* last_min) {
+    team = std::max(1, team);
+    order.assign((size_t)cap, 0);
+    const Long vis = -2 - id;
+    order[0] = root;
+    c.level[root] = 0;
+    c.set_mk(root, vis);
+    Long lo = 0, hi = 1, lev = 0;                       // frontier = order[lo, hi): written by thread 0 between barriers
+    std::vector<std::vector<Long>> local((size_t)team);
+    std::vector<Long> sizes((size_t)team, 0);
+    SpinBarrier bar;
+    bar.n = team;
+    bool done = false;
+    auto body = [&](int t) {
+        std::vector<Long>& mine = local[(size_t)t];
+        for (;;) {
+            const Long F = hi - lo;
+            const Long a = lo + F * t / team, b = lo + F * (t + 1) / team;
+            mine.clear();
+            for (Long h = a; h < b; ++h) {
+                const Long v = order[(size_t)h];
+                for (Long p = c.Ap[v]; p < c.Ap[v + 1]; ++p) {
+                    const Long w = c.Ai[p];
+                    if (c.mk(w) != id) continue;
+                    Long expect = id;
+                    if (__atomic_compare_exchange_n(&c.mark[w], &expect, vis, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                        c.level[w] = lev + 1;
+                        mine.push_back(w);
+                    }
+                }
+            }
+            sizes[(size_t)t] = (Long)mine.size();
+            bar.wait();
+            Long off = hi, total = 0;
+            for (int q = 0; q < team; ++q) { if (q < t) off += sizes[(size_t)q]; total += sizes[(size_t)q]; }
+            for (size_t k = 0; k < mine.size(); ++k) order[(size_t)off + k] = mine[k];
+            bar.wait();
+            if (t == 0) {
+                if (total == 0) done = true;
+                else { lo = hi; hi += total; ++lev; }
+            }
+            bar.wait();
+            if (done) return;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < team; ++t) th.emplace_back(body, t);
+    body(0);
+    for (std::thread& x : th) x.join();
+    order.resize((size_t)hi);
+    Long mn = order[(size_t)lo];
+    for (Long h = lo; h < hi; ++h) mn = std::min(mn, order[(size_t)h]);
+    *last_min = mn;
+    // marks: visited -> final_mark (split among the team)
+    {
+        const Long N = hi;
+        auto fin = [&](int t) { for (Long h = N * t / team; h < N * (t + 1) / team; ++h) c.set_mk(order[(size_t)h], final_mark); };
+        std::vector<std::thread> th2;
+        for (int t = 1; t < team; ++t) th2.emplace_back(fin, t);
+        fin(0);
+        for (std::thread& x : th2) x.join();
+    }
+    return lev + 1;
+}
+
+// one connected big piece: `comp` sorted by vertex number, all marked with one id; `root`: where the level structure starts (the
+// smallest vertex of the last level of the sweep that found the component = the second sweep of a pseudo-peripheral search)
+void nd_component_big(NdCtx& c, std::vector<Long>& comp, Long pos, int team, Long root) {
+    const Long id = c.mk(comp[0]);
+    std::vector<Long> order;
+    Long last_min = 0;
+    const Long nlev = nd_bfs_team(c, id, root, team, (Long)comp.size(), id, order, &last_min);
+    { std::vector<Long>().swap(order); }
+    if (nlev < 3) {         // (nearly) complete graph: no useful separator
+        for (Long v : comp) { c.out[pos++] = v; c.set_mk(v, -1); }
+        return;
+    }
+    std::vector<Long> cnt((size_t)nlev, 0);
+    for (Long v : comp) cnt[(size_t)c.level[v]]++;
+    Long best = 1, best_cost = -1, below = cnt[0], below0 = cnt[0];
+    const Long total = (Long)comp.size();
+    for (Long l = 1; l + 1 < nlev; ++l) {
+        const Long above = total - below - cnt[(size_t)l];
+        const Long cost = std::max(below, above) + cnt[(size_t)l];
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = l; below0 = below; }
+        below += cnt[(size_t)l];
+    }
+    std::vector<Long> A, B, Sep;
+    const Long ida = c.next_id++, idb = c.next_id++;
+    A.reserve((size_t)below0);
+    B.reserve((size_t)(total - below0 - cnt[(size_t)best]));
+    Sep.reserve((size_t)cnt[(size_t)best]);
+    for (Long v : comp) {                                   // sorted in, sorted out
+        if (c.level[v] < best) { A.push_back(v); c.set_mk(v, ida); }
+        else if (c.level[v] > best) { B.push_back(v); c.set_mk(v, idb); }
+        else Sep.push_back(v);
+    }
+    for (Long v : Sep) c.set_mk(v, -1);
+    { std::vector<Long>().swap(comp); }
+    const Long posA = pos, posB = pos + (Long)A.size(), posS = posB + (Long)B.size();
+    const int team_a = std::max(1, team / 2), team_b = std::max(1, team - team_a);
+    std::thread helper;
+    if (!A.empty() && !B.empty() && team >= 2) {
+        c.helpers.fetch_add(1);
+        helper = std::thread([&c, &A, posA, team_a] { nd_recurse(c, A, posA, team_a); });
+    } else if (!A.empty()) nd_recurse(c, A, posA, team);
+    if (!B.empty()) nd_recurse(c, B, posB, helper.joinable() ? team_b : team);
+    if (helper.joinable()) { helper.join(); c.helpers.fetch_sub(1); }
+    Long q = posS;
+    for (Long v : Sep) c.out[q++] = v;
+}
+
 
 // `verts`: vertices carrying one common mark, to be written to out[pos ..).  Its connected components are peeled off one after
 // the other (iteratively: a diagonal matrix has n components) and dissected.
-void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos) {
+void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team) {
     const Long id = c.mk(verts[0]);
+    // big pieces (the input list is sorted by vertex number -- the whole graph is, and the big path only hands down filtered lists)
+    while ((Long)verts.size() >= ND_PAR_MIN) {
+        std::vector<Long> order;
+        Long last_min = 0;
+        const Long cid = c.next_id++;
+        (void)nd_bfs_team(c, id, verts[0], team, (Long)verts.size(), cid, order, &last_min);
+        std::vector<Long> comp, rest;
+        if (order.size() == verts.size()) comp.swap(verts);
+        else {
+            for (Long v : verts) (c.mk(v) == cid ? comp : rest).push_back(v);
+            verts.swap(rest);
+        }
+        { std::vector<Long>().swap(order); }
+        const Long sz = (Long)comp.size();
+        if (sz >= ND_PAR_MIN) nd_component_big(c, comp, pos, team, last_min);
+        else {
+            // a small component of a big piece: the sequential code wants it in BFS order from some vertex of it
+            std::vector<Long> o2;
+            nd_bfs(c, cid, comp[0], o2);
+            nd_component(c, o2, pos);
+        }
+        pos += sz;
+        if (verts.empty()) return;
+    }
     std::vector<Long> comp;
     for (Long v : verts) {
         if (c.mk(v) != id) continue;          // already ordered as part of an earlier component
@@ -796,12 +958,12 @@ void nd_component(NdCtx& c, std::vector<Long>& comp, Long pos) {
     const Long posA = pos, posB = pos + (Long)A.size(), posS = posB + (Long)B.size();
     std::thread helper;
     if (!A.empty() && !B.empty() && (Long)A.size() >= 20000 && c.helpers.fetch_add(1) < c.max_helpers)
-        helper = std::thread([&c, &A, posA] { nd_recurse(c, A, posA); });
+        helper = std::thread([&c, &A, posA] { nd_recurse(c, A, posA, 1); });
     else {
         if (!A.empty() && !B.empty() && (Long)A.size() >= 20000) c.helpers.fetch_sub(1);      // no free helper: undo the claim
-        if (!A.empty()) nd_recurse(c, A, posA);
+        if (!A.empty()) nd_recurse(c, A, posA, 1);
     }
-    if (!B.empty()) nd_recurse(c, B, posB);
+    if (!B.empty()) nd_recurse(c, B, posB, 1);
     if (helper.joinable()) { helper.join(); c.helpers.fetch_sub(1); }
     Long q = posS;
     for (Long v : Sep) c.out[q++] = v;
@@ -811,6 +973,9 @@ void nd_component(NdCtx& c, std::vector<Long>& comp, Long pos) {
 // Cp/Ci: any triangle (or both) of the symmetric pattern; the pattern is symmetrised.  perm[new] = old.
 int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm) {
     if (n < 0 || !Cp || (n > 0 && !Ci) || !perm || leaf < 1) return 1;
+    const bool tr_nd = getenv("SF_TRACE") != nullptr;
+    auto now_nd = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_nd0 = now_nd();
     std::vector<Long> Ap(n + 1, 0), Ai;
     for (Long j = 0; j < n; ++j)
         for (Long p = Cp[j]; p < Cp[j + 1]; ++p) {
@@ -828,13 +993,15 @@ int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm)
                 if (i != j) { Ai[fill[i]++] = j; Ai[fill[j]++] = i; }
             }
     }
+    const double t_nd1 = now_nd();
     NdCtx c{Ap, Ai, std::vector<Long>(n, 0), std::vector<Long>(n, 0), perm, leaf};
     c.max_helpers = analysis_threads() - 1;
     if (n == 0) return 0;
     std::vector<Long> all(n);
     for (Long v = 0; v < n; ++v) all[v] = v;
     for (Long v = 0; v < n; ++v) perm[v] = -1;
-    nd_recurse(c, all, 0);    // recursion depth = dissection depth, O(log n) for balanced level separators
+    nd_recurse(c, all, 0, analysis_threads());    // recursion depth = dissection depth, O(log n) for balanced level separators
+    if (tr_nd) fprintf(stderr, "[sparseframe-hip]   ordering: adjacency %.1f ms, dissection %.1f ms (%d threads)\n", t_nd1 - t_nd0, now_nd() - t_nd1, analysis_threads());
     for (Long v = 0; v < n; ++v)
         if (perm[v] < 0) return 2;
     return 0;

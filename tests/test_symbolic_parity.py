@@ -113,12 +113,26 @@ for k in ("Lp", "Li", "LTi", "Up", "Ui", "UTp", "UTi", "Super", "Lsi", "Lx", "Ux
 g = 46
 n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
 out["graph_nd_perm"] = hashlib.sha256(sf.graph_nd_perm(n, Cp, Ci).tobytes()).hexdigest()
+# pieces of >= 100,000 vertices share their BFS among a TEAM of threads (round 3): 62^3 = 238k vertices (the top piece and its two
+# halves take that path), and two disconnected 48^3 grids (two big components of one big piece)
+import numpy as np
+g = 62
+n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
+p = sf.graph_nd_perm(n, Cp, Ci)
+assert sorted(p.tolist()) == list(range(n))
+out["graph_nd_perm_team"] = hashlib.sha256(p.tobytes()).hexdigest()
+g = 48
+n1, Cp1, Ci1, Cx1 = sf.gen.laplacian_lower(g, g, g)
+Cp2 = np.concatenate([Cp1, Cp1[1:] + Cp1[-1]]); Ci2 = np.concatenate([Ci1, Ci1 + n1])
+p = sf.graph_nd_perm(2 * n1, Cp2, Ci2)
+assert sorted(p.tolist()) == list(range(2 * n1))
+out["graph_nd_perm_team_2comp"] = hashlib.sha256(p.tobytes()).hexdigest()
 print(json.dumps(out))
 '''
     res = []
-    for T in ("1", "8"):
+    for T in ("1", "3", "8"):
         env = dict(os.environ, SF_ANALYZE_THREADS=T)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE), timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert res[0] == res[1]
+    assert res[0] == res[1] == res[2]
