@@ -502,10 +502,13 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
             // the host copy must still be what the devices hold: EVERY panel's fingerprint over the caller's array against the one
             // every rank that stores the panel computes over its own copy (k_factor_hash; Cholesky and LU)
             const size_t N = R.parts.size();
+            const auto tv0 = std::chrono::steady_clock::now();
             if (mode == 1) {
                 sf_chol_plan* P0 = R.parts[0];
                 std::vector<uint64_t> hh;
                 host_panel_hashes(Lsx_host, P0->h_Lsxp.data(), P0->nsuper, hh);
+                if (trace) fprintf(stderr, "[sparseframe-hip] resident solve: host fingerprints %.1f ms\n",
+                                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count());
                 for (size_t r = 0; r < N; ++r) {
                     const uint64_t* dh = nullptr;
                     if (sf_plan_panel_hashes(R.parts[r], &dh) != SF_OK) return why("a rank's fingerprints could not be computed");
@@ -516,11 +519,15 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
                         }
                 }
             }
+            const auto tv1 = std::chrono::steady_clock::now();
             std::vector<int> rcs(N, SF_OK);
             std::vector<std::thread> th;
             for (size_t r = 0; r < N; ++r)
                 th.emplace_back([&, r] { rcs[r] = sf_chol_plan_solve_distributed(R.parts[r], R.comms[r], b, x); });
             for (std::thread& t : th) t.join();
+            if (trace) fprintf(stderr, "[sparseframe-hip] resident solve: verification %.1f ms, distributed solve %.1f ms\n",
+                               std::chrono::duration<double, std::milli>(tv1 - tv0).count(),
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv1).count());
             for (size_t r = 0; r < N; ++r)
                 if (rcs[r]) return why("the distributed solve failed");
             ++g_resident_solves;

@@ -306,8 +306,9 @@ k_factor_hash(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsi
               const int64_t* __restrict__ RefXp, int32_t nsuper, const double* __restrict__ PL, const double* __restrict__ PU, int lu,
               int64_t total, int64_t chunk, unsigned long long* __restrict__ H) {
     const int64_t begin = (int64_t)blockIdx.x * chunk, end = min(begin + chunk, total);
-    int64_t e = begin + threadIdx.x;
-    if (e >= end) return;
+    if (begin >= end) return;               // (whole workgroup)
+    const bool idle = begin + threadIdx.x >= end;           // last chunk: these threads add nothing but join the barriers below
+    int64_t e = idle ? end - 1 : begin + threadIdx.x;
     int lo = 0, hi = nsuper;                // largest s with RefXp[s] <= e
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -317,6 +318,7 @@ k_factor_hash(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsi
     unsigned long long acc = 0;
     int64_t s_end = RefXp[s + 1], s_beg = RefXp[s], xp = Xp[s];
     int64_t nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+    if (idle) e = end;                      // nothing to add; stays for the barriers below
     for (; e < end; e += 256) {
         if (e >= s_end) {
             if (acc) atomicAdd(&H[s], acc);
@@ -325,7 +327,10 @@ k_factor_hash(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsi
             s_end = RefXp[s + 1]; s_beg = RefXp[s]; xp = Xp[s];
             nscol = Super[s + 1] - Super[s]; nsrow = Lsip[s + 1] - Lsip[s];
         }
-        if (xp < 0) continue;               // not stored on this rank
+        if (xp < 0) {                       // not stored on this rank: on to this thread's first value behind the panel
+            e += ((s_end - e + 255) / 256 - 1) * 256;
+            continue;
+        }
         const int64_t off = e - s_beg;
         double v;
         if (!lu) {
@@ -339,7 +344,21 @@ k_factor_hash(const int32_t* __restrict__ Super, const int64_t* __restrict__ Lsi
         }
         acc += (unsigned long long)__double_as_longlong(v) * ((2ull * (unsigned long long)e + 1ull) * 0x9E3779B97F4A7C15ull);
     }
-    if (acc) atomicAdd(&H[s], acc);
+    // end of the chunk: inside a big panel all 256 threads hold partial sums of ONE supernode -- one atomic per workgroup instead of
+    // 256 on the same word (the root panel alone would otherwise take 59 M serialised atomics); mixed workgroups add per thread
+    __shared__ int s_first;
+    __shared__ unsigned long long s_part[4];
+    if (threadIdx.x == 0) s_first = s;
+    __syncthreads();
+    const bool uniform = __syncthreads_and(s == s_first) != 0;
+    if (!uniform) { if (acc) atomicAdd(&H[s], acc); return; }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (tot) atomicAdd(&H[s], tot);
+    }
 }
 
 void launch_factor_hash(const int32_t* Super, const int64_t* Lsip, const int64_t* Xp, const int64_t* RefXp, int32_t nsuper,
