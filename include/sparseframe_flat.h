@@ -305,10 +305,10 @@ int64_t sf_handlers_perturbed_pivots(const sf_float *Lsx_host);
  * host copy.  Solves on the device(s) (b, x in the permuted numbering, n doubles each way) when the plan still holds THAT factorization
  * (generation counter) AND the caller's array still is what the device holds: a 64-bit fingerprint of every panel -- sum over its
  * values of bits(v) * (2 index + 1) * K mod 2^64, any single changed value changes it -- is computed over the WHOLE host array (one
- * threaded pass, ~0.2 s for 30 GB) and compared with the device's (computed once per factorization, about one read of the factor).
+ * threaded pass, ~0.1 s for 30 GB) and compared with the device's (computed once per factorization, about one read of the factor).
  * Otherwise returns SF_ERR_ARG and the caller solves on the host as the reference does (C:3036-3139).
  * sf_handlers_set_resident_solve(mode): 0 = never (always the host sweep), 1 = verified as above (default), 2 = trusted: the caller
- * guarantees it does not modify Lsx between factorize and solve; the comparison is skipped (0.03 s instead of 0.25 s at 128^3).
+ * guarantees it does not modify Lsx between factorize and solve; the comparison is skipped (0.02 s instead of 0.13 s at 128^3).
  * SF_SOLVE=host in the environment forces the host solve.  forget: the host copy is being freed. */
 int sf_handlers_set_resident_solve(int mode);
 /* 1 if this build keeps the A/B environment switches of finished experiments (make EXP=1), 0 for a release build */

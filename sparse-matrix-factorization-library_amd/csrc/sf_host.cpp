@@ -475,11 +475,14 @@ int SparseFrame_cleanup_matrix(struct matrix_info_struct* mi) {  // C:3268-3321
     SF_FREE(Perm); SF_FREE(Post); SF_FREE(Parent); SF_FREE(ColCount);
     SF_FREE(Super); SF_FREE(SuperMap); SF_FREE(Sparent); SF_FREE(LeafQueue);
     SF_FREE(Lsip); SF_FREE(Lsxp); SF_FREE(Lsi);
-    free_big_async((void**)&mi->Lsx, (size_t)(mi->xsize > 0 ? mi->xsize : 0) * sizeof(sf_float));
+    sf_float* big_lsx = mi->Lsx;            // released LAST (below): a concurrent munmap of tens of GB makes every other munmap wait
+    const size_t big_bytes = (size_t)(mi->xsize > 0 ? mi->xsize : 0) * sizeof(sf_float);
+    mi->Lsx = nullptr;
     SF_FREE(ST_Map); SF_FREE(ST_Pointer); SF_FREE(ST_Index);
     SF_FREE(Aoffset); SF_FREE(Moffset);
     SF_FREE(workspace);
     SF_FREE(Bx); SF_FREE(Xx); SF_FREE(Rx);
+    free_big_async((void**)&big_lsx, big_bytes);
     // keep the timers and the residual readable after clean-up, as the reference's driver
     // prints them after calling this (C:3423-3433)
     const double rt = mi->readTime, at = mi->analyzeTime, ft = mi->factorizeTime, st = mi->solveTime;

@@ -354,9 +354,12 @@ int SparseFrame_cleanup_matrix(struct matrix_info_struct* mi) {   // L:3860-3922
     SF_FREE(PivInv); SF_FREE(Perm); SF_FREE(Post); SF_FREE(Parent); SF_FREE(ColCount);
     SF_FREE(Super); SF_FREE(SuperMap); SF_FREE(Sparent); SF_FREE(LeafQueue);
     SF_FREE(Lsip); SF_FREE(Lsxp); SF_FREE(Lsi);
-    free_big_async((void**)&mi->Lsx, (size_t)(mi->xsize > 0 ? mi->xsize : 0) * sizeof(sf_float));
+    sf_float* big_lsx = mi->Lsx;            // released LAST (below): a concurrent munmap of tens of GB makes every other munmap wait
+    const size_t big_bytes = (size_t)(mi->xsize > 0 ? mi->xsize : 0) * sizeof(sf_float);
+    mi->Lsx = nullptr;
     SF_FREE(ST_Map); SF_FREE(ST_Pointer); SF_FREE(ST_Index); SF_FREE(Aoffset); SF_FREE(Moffset);
     SF_FREE(workspace); SF_FREE(Bx); SF_FREE(Xx); SF_FREE(Rx);
+    free_big_async((void**)&big_lsx, big_bytes);
     const double rt = mi->readTime, at = mi->analyzeTime, ft = mi->factorizeTime, st = mi->solveTime, res = mi->residual;
     SparseFrame_initialize_matrix(mi);
     mi->readTime = rt; mi->analyzeTime = at; mi->factorizeTime = ft; mi->solveTime = st; mi->residual = res;
