@@ -450,9 +450,24 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         const int b = std::min(sf::NB, nscol - diag);
                         flag_of.push_back(n_flags);
                         // Cholesky: J = diag (no left-looking update): the diagonal block arrives up to date, see k_step
-                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, lu ? J : diag, diag, b, diag, b, n_flags++, 0, (int32_t)(steps.size() - d0), 0, (int32_t)Super[s], 0});
+                        // LU: the diagonal block's own left-looking update is cut in two -- its far part (columns [J, diag - 64): final
+                        // before the PREVIOUS step starts) was applied by a pre-update task of that step's launch (below), the
+                        // diagonal workgroup only applies the last 64 columns before it factors
+                        steps.push_back(StepTask{XP[s], XP[s] + (lu ? ushift : 0), nsrow, lu ? (ti >= 2 ? diag - sf::NB : J) : diag, diag, b, diag, b, n_flags++, 0, (int32_t)(steps.size() - d0), 0, (int32_t)Super[s], 0});
                         slot_of.push_back((int32_t)(steps.size() - 1 - d0));
                         if (ti > 0) p->flops_panel_gemm += (lu ? 2.0 : 1.0) * ((double)b * (b + 1) * (diag - J) + 2.0 * (nsrow - diag - b) * (double)b * (diag - J));
+                    }
+                    if (lu && ti >= 1 && ti + 1 < ninner) {
+                        // pre-update tasks (mode bit 1): the far part of the NEXT step's diagonal-block update, K = [J, diag) -- the
+                        // columns of the steps before this one, final when this launch starts.  Right behind the diagonal tasks:
+                        // they never wait and are the longest tasks of the launch.
+                        const int dnext = diag + sf::NB;
+                        for (sf_long s : Sl) {
+                            const int nscol = (int)(Super[s + 1] - Super[s]), nsrow = (int)(Lsip[s + 1] - Lsip[s]);
+                            if (dnext >= nscol) continue;
+                            const int bn = std::min(sf::NB, nscol - dnext);
+                            steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, dnext, bn, dnext, bn, -1, 2, 0, 0, (int32_t)Super[s], 0});
+                        }
                     }
                     size_t si = 0;
                     for (sf_long s : Sl) {

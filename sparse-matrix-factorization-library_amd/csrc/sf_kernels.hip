@@ -166,13 +166,16 @@ __device__ __forceinline__ void getrf_panel_wave(double (&a)[W], int lane, int J
         const int J = J0 + j;
         int p = J;
         if (tol > 0.0 && J < b) {               // wave-uniform: no pivot search when pivoting is off or in the padding
-            // cheap test first: an upper bound of max |a_ij| from ONE reduction over the high words; the exact arg-max (a second
-            // reduction and a ballot) only when the natural row fails it
+            // The natural row keeps the pivot iff it is still free, non-zero, and NO free row has tol * |a_ij| > |a_jj| -- one
+            // multiply, one compare and a ballot; no reduction.  (fl(tol * x) is monotonic in x, so this IS |a_jj| >= tol * max:
+            // the decision of the reduction it replaces, which cost 2 us per 16-column panel.)  A NaN counts as larger.  Only when
+            // the natural row fails is the arg-max looked for (two 32-bit DPP reductions and a ballot).
             const double nat = readlane_dyn_f64(a[j], J);
-            const bool nat_free = ((__ballot(active) >> J) & 1ull) != 0;
-            const uint32_t mhi = wave_max_u32(active ? (((uint32_t)__double2hiint(a[j]) & 0x7fffffffu) + 1u) : 0u);
-            const double m_ub = __hiloint2double((int)(mhi - 1u), -1);
-            if (!(nat_free && mhi != 0u && fabs(nat) >= tol * m_ub && nat != 0.0)) {
+            const unsigned long long act = __ballot(active);
+            const bool nat_free = ((act >> J) & 1ull) != 0;
+            const double anat = fabs(nat);
+            const unsigned long long larger = __ballot(active && !(tol * fabs(a[j]) <= anat));
+            if (!(nat_free && larger == 0ull && nat != 0.0)) {
                 double m;
                 const int pm = wave_argmax_abs(a[j], active, &m);
                 if (!(nat_free && fabs(nat) >= tol * m && nat != 0.0) && pm >= 0) p = pm;
@@ -1280,6 +1283,14 @@ constexpr int ST_KC = 32;                // K chunk of the update's LDS-staged o
 constexpr int ST_XLD = ST_ROWS + 16;     // its LDS row stride
 constexpr int ST_SPIN_LIMIT = 1 << 22;   // ~ seconds
 
+#ifdef SF_EXP_STEP_STAMPS       // tools/experiments/step_stamps.sh: where the diagonal workgroup of a step spends its time (100 MHz stamps)
+__device__ unsigned long long* g_step_stamps = nullptr;
+void exp_set_step_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_stamps), &p, sizeof(p)); }
+#define ST_STAMP(slot) do { if (is_diag && tid == 0 && g_step_stamps) g_step_stamps[slot] = wall_clock64(); } while (0)
+#else
+#define ST_STAMP(slot) do { } while (0)
+#endif
+
 template <bool LU>
 __global__ void __launch_bounds__(256, LU ? SF_LU_STEP_WGS : 3)   // LU: the unblocked GETRF keeps a 64-value row per lane
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info,
@@ -1301,14 +1312,25 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     // chip, whatever order the hardware dispatches the grid in and whatever else shares the GPU.
     __shared__ int s_ticket;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SF_EXP_STEP_STAMPS
+    const unsigned long long st_entry = wall_clock64();
+#endif
     if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const StepTask t = tasks[__builtin_amdgcn_readfirstlane(s_ticket)];
-    const bool is_diag = t.row0 == t.diag;
+    // LU, mode bit 1: a PRE-UPDATE task -- the far part (columns [J, diag - 64)) of the left-looking update of the diagonal block of
+    // the NEXT step, done one launch early and off the critical path (everything it reads is final when this launch starts); that
+    // step's diagonal workgroup then only applies the last 64 columns before it factors (see the task list in sf_chol_plan.hip)
+    const bool is_pre = LU && (t.mode & 2);
+    const bool is_diag = t.row0 == t.diag && !is_pre;
+#ifdef SF_EXP_STEP_STAMPS
+    if (is_diag && tid == 0 && g_step_stamps) g_step_stamps[0] = st_entry;
+#endif
+    ST_STAMP(1);
     const int fr = lane & 15, fk = lane >> 4;
     const int64_t ld = t.ld;
     const int b = t.b, nrows = t.nrows;
-    const int nhp = (t.diag - t.J) / NB;             // K = 64 nhp = 2 nhp chunks of ST_KC = 32
+    const int nhp = ((is_pre ? t.diag - NB : t.diag) - t.J) / NB;             // K = 64 nhp = 2 nhp chunks of ST_KC = 32
     double* __restrict__ Ag = Lsx + t.panel + t.row0 + (int64_t)t.diag * ld;          // this tile: rows row0.., columns diag..
     // the diagonal block in the panel the OTHER operand comes from (Cholesky: the same panel; LU: L rows are updated with
     // and solved against the U^T panel's block and vice versa)
@@ -1385,6 +1407,26 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         }
     }
 
+    if (is_pre) {
+        // D <- D - (far part of the update), in place: D(ci,cj) lives in the L panel for cj < ci, in the U^T panel (transposed)
+        // otherwise.  One writer: this launch's row tasks write other columns of these rows, the block's own step comes later.
+        double* __restrict__ Dw = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
+        const int ci = 16 * wave + fr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cj = 16 * q + fk + 4 * r;
+                const int cic = min(ci, b - 1), cjc = min(cj, b - 1);
+                const double dl = Ag[cic + (int64_t)cjc * ld], du = Dw[cjc + (int64_t)cic * ld];       // unconditional, clamped
+                if (ci < b && cj < b) {
+                    if (cj < ci) Ag[ci + (int64_t)cj * ld] = dl - acc[q][r];
+                    else Dw[cj + (int64_t)ci * ld] = du - acc[q][r];
+                }
+            }
+        return;
+    }
+
     // Row task: the updated tile stays in the MFMA accumulator layout (wave w: rows 16 w + fr, column tile q:
     // columns 16 q + fk + 4 r), which is also the B-operand layout of the next MFMA -- the solve below runs on registers
     double4_t rt[4];
@@ -1438,6 +1480,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         __shared__ int s_piv[NB], s_pos[NB];
         if (tid < NB) s_pos[tid] = -1;
         __syncthreads();
+        ST_STAMP(2);
         bool bad = false, active = lane < b;
         int np = 0, pos = lane;
 #pragma unroll 1
@@ -1493,7 +1536,9 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 }
             }
             __syncthreads();
+            ST_STAMP(3 + q);
         }
+        ST_STAMP(6);
         if (wave == 0) {
             if (bad && lane == 0) atomicOr(info, 1);
             if (np > 0 && lane == 0) atomicAdd(pc.nperturb, np);
@@ -1522,6 +1567,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             }
         }
         __syncthreads();
+        ST_STAMP(7);
         {
             // inverses of the 16 x 16 diagonal sub-blocks the row tasks solve against: of U11^T (lower, for the L rows) at
             // tinv[slot][0][w], of the unit-lower L11 (for the U^T rows) at tinv[slot][1][w]; wave w does block w of both
@@ -1548,6 +1594,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 for (int r = 0; r < 16; ++r) { out[r] = wu[r]; out[1024 + r] = wl[r]; }
             }
         }
+        ST_STAMP(8);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -1555,10 +1602,12 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flags + t.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        ST_STAMP(9);
         return;
     }
     if (is_diag) {
         __syncthreads();
+        ST_STAMP(2);
         // POTRF of the updated block, blocked by 16 columns.  Panel part: wave 0, lane r holds row r of the 16 columns
         // (k_potrf_block's scheme; the column scaling of all 64 rows comes with it, so there is no separate TRSM).
         // Trailing part: every wave updates its 16 rows of the columns to the right with MFMA out of LDS,
@@ -1610,7 +1659,9 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 }
             }
             __syncthreads();
+            ST_STAMP(3 + q);
         }
+        ST_STAMP(6);
         if (bad && wave == 0 && lane == 0) atomicOr(info, 1);
         // Inverses of the four 16 x 16 diagonal sub-blocks of L (what MAGMA-style TRSMs use): wave w inverts block w by
         // forward substitution, lane j (< 16) holds column j of the inverse, the entries of T are LDS broadcasts.  The
@@ -1637,6 +1688,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 for (int r = 0; r < 16; ++r) out[r] = wv[r];
             }
         }
+        ST_STAMP(8);
         // publish: EVERY storing wave drains, the barrier collects them, then ONE device-scope release by lane 0 and
         // the flag (the explicit waits keep the order whatever the compiler does with the fence's own wait)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1648,6 +1700,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flags + t.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        ST_STAMP(9);
         return;
     }
 
