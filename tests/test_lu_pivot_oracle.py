@@ -171,3 +171,23 @@ def test_zero_diagonal_and_perturbation(oracle):
     S1 = sf.analyze(*dense_csc(D + 0.0), None, 1 << 30, "lu", False)
     Lsx, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S1, tol=0.1)
     assert nper >= 1 and info == 0
+
+
+def test_oracle_reproduces_the_committed_lu_vectors(oracle):
+    """tests/golden/lu_small.json on the CPU: the product's analysis gives the committed integers, the oracle (both the no-pivot path
+    and the pivoted one) the committed pivots and values -- the same file the GPU test compares the HIP path with"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lu_small.json")) as f:
+        G = json.load(f)
+    for name, g in G.items():
+        S = sf.analyze(g["n"], g["Cp"], g["Ci"], g["Cx"], g["perm"], g["devSlotSize"], "lu", g["symmetric"])
+        for k in ("Super", "Lsip", "Lsxp", "Lsi", "Perm"):
+            assert np.array_equal(getattr(S, k), np.asarray(g[k], dtype=np.int64)), (name, k)
+        if g["pivpos"] is None:
+            Lsx, info, _ = oracle.lu_factorize(S)
+            assert info == 0
+        else:
+            Lsx, info, pivpos, _, nper = oracle.lu_factorize_pivot(S, tol=g["tol"], perturb=g["perturb"])
+            assert info == 0 and nper == g["perturbed"] and np.array_equal(pivpos, np.asarray(g["pivpos"]))
+        assert rel_err(Lsx, np.asarray(g["Lsx"])) <= 1e-13, name
