@@ -145,7 +145,8 @@ void host_panel_hashes(const double* Lsx, const int64_t* Lsxp, int64_t nsuper, s
                 while (e >= Lsxp[s + 1]) ++s;
                 const int64_t stop = std::min(e_end, Lsxp[s + 1]);
                 uint64_t acc = 0, m = (2ull * (uint64_t)e + 1ull) * K;
-                const uint64_t* w = reinterpret_cast<const uint64_t*>(Lsx);
+                typedef uint64_t __attribute__((may_alias)) bits64;            // the doubles' bit patterns
+                const bits64* w = reinterpret_cast<const bits64*>(Lsx);
                 for (; e < stop; ++e, m += 2ull * K) acc += w[e] * m;
                 if (acc) loc.emplace_back(s, acc);
             }
