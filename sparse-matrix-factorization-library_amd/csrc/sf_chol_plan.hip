@@ -83,6 +83,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
         if (p->ev_reduced[k]) (void)hipEventDestroy(p->ev_reduced[k]);
         if (p->ev_unpacked[k]) (void)hipEventDestroy(p->ev_unpacked[k]);
     }
+    for (hipEvent_t e : p->la_events) if (e) (void)hipEventDestroy(e);
     if (p->stream2) (void)hipStreamDestroy(p->stream2);
     for (hipEvent_t e : p->dl_events)
         if (e) (void)hipEventDestroy(e);
@@ -312,6 +313,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // rank's own rounding.  Everything a chain reads is either an all-reduced sum or computed in a fixed order -- the step kernels,
     // and the look-ahead schedule's replicated near parts, which run k_gemm with whole_tiles: one addition per target element.)
     if (const char* env = getenv("SF_LOOKAHEAD")) p->lookahead = atoi(env) != 0;      // 0: the round-1 schedule (tests cover both)
+    if (const char* env = sf_exp_env("SF_LOOKAHEAD1")) p->lookahead1 = atoi(env) != 0 && nranks == 1 && !p->partial;
+    if (const char* env = sf_exp_env("SF_LOOKAHEAD1_GRID")) p->la_grid = std::max(0, atoi(env));
+    int n_la_events = 0;
     // The sweep: one set of independent supernodes at a time -- phase 0: a level of the owned subtrees; phase 1: the top
     // supernodes of one level that share one group of ranks (ascending mask: every rank meets the sets it shares with
     // another rank in the same order, so the groups' collectives cannot wait for each other in a circle).
@@ -393,10 +397,21 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         // the reduce point of block jo, executed in full by every rank: 512 columns of K).  The far part is all a block's sum over
         // the ranks has to wait for, so that sum travels while the chain of block jo-1 runs (sf_chol_plan_factorize_distributed).
         const bool ahead = shared && p->lookahead && LS.share_cnt > 1;
+        // ONE GPU (experiment, SF_LOOKAHEAD1, EXP builds only): the same cut, the far part on the plan's second stream -- far(jo+2) needs
+        // the chain of block jo only, so it runs beside near(jo+1) + chain(jo+1); events order the two lanes.  MEASURED AND NOT ADOPTED:
+        // 546.7 ms against 540.7 at 128^3 with the full side grid, 549.9 / 567.8 / 613.6 with 448 / 384 / 256 workgroups
+        // (profiles/r03_m_one_gpu_lookahead.txt; DESIGN 5.2: a persistent GEMM grid leaves no registers for the chain's workgroups)
+        const bool ahead1 = !shared && p->lookahead1 && nouter >= 3;
+        std::vector<int> chain_ev(ahead1 ? nouter : 0, -1), far_ev(ahead1 ? nouter : 0, -1);
         constexpr int KT_BLOCK = sf::OUTER_NB / sf::GEMM_BK;
         for (int jo = 0; jo < nouter; ++jo) {
             const int J = jo * sf::OUTER_NB;
-            if (jo > 0 && !ahead) outer_gemm(J, 0, -1, shared, true);
+            if (jo > 0 && !ahead && !ahead1) outer_gemm(J, 0, -1, shared, true);
+            if (ahead1 && jo > 0) {
+                const size_t l = p->launches.size();
+                outer_gemm(J, (jo - 1) * KT_BLOCK, jo * KT_BLOCK, false, true);        // block jo-1 -> block jo (main lane)
+                if (p->launches.size() > l && far_ev[jo] >= 0) p->launches.back().wait_ev = far_ev[jo];
+            }
             if (shared) {
                 // reduce point: block column jo of every panel of the set is complete up to the sum over the group's ranks
                 if (!p->segments.empty()) p->segments.back().l1 = p->launches.size();
@@ -540,6 +555,18 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             for (sf_long s : Sl)
                 if (J < Super[s + 1] - Super[s]) blk_ready[blk_first[s] + jo] = p->launches.size();
             if (ahead && jo + 2 < nouter) outer_gemm(J + 2 * sf::OUTER_NB, 0, (jo + 1) * KT_BLOCK, true, true);    // blocks 0 .. jo -> block jo+2
+            if (ahead1 && jo + 2 < nouter && !p->launches.empty()) {
+                chain_ev[jo] = n_la_events++;
+                p->launches.back().rec_ev = chain_ev[jo];                               // the chain's last launch
+                const size_t l = p->launches.size();
+                outer_gemm(J + 2 * sf::OUTER_NB, 0, (jo + 1) * KT_BLOCK, false, true);
+                if (p->launches.size() > l) {
+                    far_ev[jo + 2] = n_la_events++;
+                    p->launches.back().lane = 1;
+                    p->launches.back().wait_ev = chain_ev[jo];
+                    p->launches.back().rec_ev = far_ev[jo + 2];
+                }
+            }
         }
         // Schur updates of every supernode of this level into its ancestors
         const int64_t g0 = (int64_t)gtasks.size(), s0 = (int64_t)stasks.size();
@@ -1079,13 +1106,19 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             if (hipMemcpy(p->d_fill, fill_tiles.data(), fb, hipMemcpyHostToDevice) != hipSuccess) { rc = SF_ERR_HIP; break; }
             p->bytes_device += fb;
         }
+        if (n_la_events > 0) {
+            bool ok = p->stream2 || new_stream(&p->stream2, hipStreamNonBlocking);
+            p->la_events.assign((size_t)n_la_events, nullptr);
+            for (hipEvent_t& e : p->la_events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { rc = SF_ERR_HIP; break; }
+        }
         if (!p->segments.empty()) {
             int64_t mx = 1;
             for (const Segment& sg : p->segments) mx = std::max(mx, sg.packed);
             p->scratch_elems = mx;
             if (hipMalloc((void**)&p->d_scratch, 2 * mx * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += 2 * mx * sizeof(double);
-            bool ok = new_stream(&p->stream2, hipStreamNonBlocking);
+            bool ok = p->stream2 || new_stream(&p->stream2, hipStreamNonBlocking);
             for (int k = 0; k < 2; ++k) {
                 ok = ok && hipEventCreateWithFlags(&p->ev_contrib[k], hipEventDisableTiming) == hipSuccess;
                 ok = ok && hipEventCreateWithFlags(&p->ev_reduced[k], hipEventDisableTiming) == hipSuccess;
@@ -1404,8 +1437,13 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
     }
     mark();
     std::vector<int> kinds;
+    hipStream_t const st_main = st;
     for (size_t li = l0; li < l1; ++li) {
         const Launch& L = p->launches[li];
+        // one-GPU look-ahead: a lane-1 launch goes to the second stream; events order the lanes.  Under profiling everything stays on
+        // the main stream (per-launch events need one stream): the profiled breakdown is that of the serial schedule.
+        st = (L.lane == 1 && !p->profiling && p->stream2) ? p->stream2 : st_main;
+        if (L.wait_ev >= 0 && !p->profiling) HIP_TRY(hipStreamWaitEvent(st, p->la_events[(size_t)L.wait_ev], 0));
         switch (L.kind) {
             case 0:
                 if (p->lu) sf::launch_getrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->xC, p->d_info, pc, st);
@@ -1433,10 +1471,12 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 }
                 sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, u0, u1,
                                 L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, p->gemm_dynamic ? p->d_info + 1 + L.ticket : nullptr, st,
-                                (L.whole_tiles && !L.split) ? 1 : 0);
+                                (L.whole_tiles && !L.split) ? 1 : 0, (L.lane == 1 && !p->profiling) ? p->la_grid : 0);
                 break;
             }
         }
+        if (L.rec_ev >= 0 && !p->profiling) HIP_TRY(hipEventRecord(p->la_events[(size_t)L.rec_ev], st));
+        st = st_main;
         if (p->profiling) { kinds.push_back(L.kind); mark(); }
         if (p->dl_active) HIP_TRY(dl_publish(p, li + 1));
     }

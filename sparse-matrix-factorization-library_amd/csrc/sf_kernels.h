@@ -153,7 +153,7 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
 // the whole-tile rounds, or nullptr for the static deal; whole_tiles != 0 (only with u_lo = 0, u_hi = all units): no tile is split by
 // units -- an order-independent (bit-reproducible) result, for launches that several ranks execute redundantly
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st, int whole_tiles = 0);
+                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st, int whole_tiles = 0, int grid_cap = 0);
 
 // Schur updates with K <= SU_MAXK: tasks are SU_TM x SU_TN tiles (GemmTask.tm / .tn in those units), one wave each
 void launch_update_small(const GemmProb* probs, const GemmTask* tasks, int ntasks, double* Lsx, const int32_t* RelMap, hipStream_t st);

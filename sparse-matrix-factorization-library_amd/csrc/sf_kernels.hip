@@ -2024,10 +2024,11 @@ void launch_build_relmaps(const GemmProb* probs, int nprobs, const int32_t* Lsi,
 }
 
 void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st, int whole_tiles) {
+                 int mode, double* Lsx, const int32_t* RelMap, int* ticket, hipStream_t st, int whole_tiles, int grid_cap) {
     if (ntasks <= 0 || u_hi <= u_lo) return;
     const uint32_t units = u_hi - u_lo;
-    const uint32_t grid = units < (uint32_t)GEMM_GRID ? units : (uint32_t)GEMM_GRID;
+    const uint32_t cap = (grid_cap > 0 && grid_cap < GEMM_GRID) ? (uint32_t)grid_cap : (uint32_t)GEMM_GRID;
+    const uint32_t grid = units < cap ? units : cap;
     // LDS-DMA staging is the default (68.9 vs 67.4 TFLOP/s at 16k x 16k x 4k, 552 vs 554 ms at 128^3); SF_GEMM_DMA=0 selects the
     // register-staged form (read per launch: the tests flip it)
     const char* e = sf_exp_env("SF_GEMM_DMA");

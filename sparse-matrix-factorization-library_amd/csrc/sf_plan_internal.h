@@ -34,6 +34,10 @@ struct Launch {
     bool whole_tiles = false;   // GEMM launch executed in full by every rank of a group: no K-splitting, bit-identical results (see k_gemm)
     double share_lo = 0.0, share_hi = 1.0;      // = share_idx / share_cnt, (share_idx + 1) / share_cnt unless the set's shares are weighted
     int ticket = 0;             // k_step launches: index of the launch's task-claim counter (d_info[1 + ticket])
+    // one-GPU look-ahead (sf_chol_plan::lookahead1): lane 1 = the plan's second stream; wait_ev / rec_ev index sf_chol_plan::la_events
+    // (the launch's stream waits for wait_ev before it, records rec_ev after it); -1 = none
+    int8_t lane = 0;
+    int wait_ev = -1, rec_ev = -1;
 };
 
 // Distributed top phase (sf_chol_plan_create_distributed): phase 1 is cut into segments.  Before a segment runs, the
@@ -166,6 +170,9 @@ struct sf_chol_plan {
     double* d_status = nullptr;    // one word: the ranks' status agreement before the first data collective (sf_multi.hip)
     double* d_scratch = nullptr;   // packed segment buffers (2 x max over the segments: segment k uses half k & 1)
     int64_t scratch_elems = 0;
+    bool lookahead1 = false;       // ONE GPU: the far part of block jo+2's update on the second stream beside the chain of block jo+1 (experiment)
+    int la_grid = 0;               // workgroups of a lane-1 GEMM (0 = the full persistent grid)
+    std::vector<hipEvent_t> la_events;
     bool lookahead = true;         // shared top panels: outer GEMM split into a far part (ahead of the previous chain) and the last block's
     hipStream_t stream2 = nullptr; // the collectives of look-ahead segments and their pack copies
     hipEvent_t ev_contrib[2] = {nullptr, nullptr}, ev_reduced[2] = {nullptr, nullptr}, ev_unpacked[2] = {nullptr, nullptr};

@@ -19,7 +19,7 @@ TOL_RESIDUAL = 1e-13
 
 EXPERIMENT_KNOBS = ("SF_DL_2D", "SF_DL_LU_PACK", "SF_GEMM_DMA", "SF_GEMM_DYNAMIC", "SF_SOLVE_BWD_AHEAD", "SF_SOLVE_BWD_FUSED",
                     "SF_SOLVE_DIAGT", "SF_SOLVE_FAR_GROUPS", "SF_SOLVE_FAR_WGS", "SF_SOLVE_FWD_AHEAD", "SF_SOLVE_FWD_FAR_FIRST",
-                    "SF_SU_MAXK", "SF_WEIGHTED_SHARES", "SF_DL_HOST_WAIT", "SF_DL_PIN", "SF_STREAM_PRIORITY")
+                    "SF_SU_MAXK", "SF_WEIGHTED_SHARES", "SF_DL_HOST_WAIT", "SF_DL_PIN", "SF_STREAM_PRIORITY", "SF_LOOKAHEAD1", "SF_LOOKAHEAD1_GRID")
 
 
 def needs_experiments(knobs):
