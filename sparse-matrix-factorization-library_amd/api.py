@@ -144,13 +144,13 @@ def validate_solution(sym, x, b=None):
         b = 1 + np.arange(n) / n
     Lp, Li, Lx = sym.Lp, sym.Li, sym.Lx
     cols = np.repeat(np.arange(n), np.diff(Lp))
+    # (np.bincount with weights: the same sums as np.add.at, an order of magnitude faster at n = 16.8 M)
     r = -np.asarray(b, dtype=np.float64).copy()
-    np.add.at(r, Li, Lx * x[cols])
+    r += np.bincount(Li, weights=Lx * x[cols], minlength=n)
     off = Li != cols
-    np.add.at(r, cols[off], Lx[off] * x[Li[off]])
-    colsum = np.zeros(n)
-    np.add.at(colsum, cols, np.abs(Lx))
-    np.add.at(colsum, Li[off], np.abs(Lx[off]))
+    r += np.bincount(cols[off], weights=Lx[off] * x[Li[off]], minlength=n)
+    ax = np.abs(Lx)
+    colsum = np.bincount(cols, weights=ax, minlength=n) + np.bincount(Li[off], weights=ax[off], minlength=n)
     return float(np.abs(r).max() / (colsum.max() * np.abs(x).max() + np.abs(b).max()))
 
 
