@@ -104,7 +104,7 @@ std::mutex& g_res_mu = *new std::mutex();
 std::unordered_map<const void*, Resident>& g_resident = *new std::unordered_map<const void*, Resident>();
 int64_t g_resident_solves = 0;      // solves served from a resident factor (tests)
 // LU pivoting policy of the struct entry points (sf_handlers_set_lu_pivoting): unset = whatever the plans were created with (the
-// reference's behaviour, no pivoting, unless SF_LU_PIVOT_TOL said otherwise); g_last_perturbed: count of the last LU factorization
+// reference's behaviour, no pivoting, unless SF_LU_PIVOT_TOL said otherwise); g_perturbed: perturbed pivots of the factorization that filled a given host array
 std::mutex& g_piv_mu = *new std::mutex();
 bool g_piv_set = false;
 double g_piv_tol = 0.0, g_piv_perturb = 0.0;

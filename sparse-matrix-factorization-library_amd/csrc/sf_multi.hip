@@ -509,7 +509,8 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
     // The ranks agree on their state before the first data collective (one 8-byte sum on the second stream, which has nothing in
     // front of it: the own subtrees enqueued above keep running meanwhile).  A rank whose copy workers or phase 0 could not be
     // set up stops HERE, and so do its peers -- instead of enqueueing all-reduces that would wait for it on the GPU for ever.
-    if ((rc = agree_status(p, comm, rc, (hipStream_t)sf_plan_stream2(p)))) {
+    // (a rank without shared segments has no second stream: its own one then)
+    if ((rc = agree_status(p, comm, rc, p->stream2 ? p->stream2 : p->stream))) {
         if (dl) (void)sf_dl_end(p);
         (void)sf_chol_plan_sync(p);
         return rc;
