@@ -12,8 +12,7 @@ def _csc_from_coo(n, rows, cols, vals):
     order = np.argsort(cols, kind="stable")
     rows, cols, vals = rows[order], cols[order], vals[order]
     Cp = np.zeros(n + 1, dtype=np.int64)
-    np.add.at(Cp, cols + 1, 1)
-    Cp = np.cumsum(Cp)
+    Cp[1:] = np.cumsum(np.bincount(cols, minlength=n))          # (np.add.at is an order of magnitude slower at 10^8 entries)
     return Cp, rows.astype(np.int64), vals.astype(np.float64)
 
 
