@@ -182,6 +182,30 @@ int sf_chol_plan_create_mapped(sf_chol_plan **plan, int device, sf_long n, sf_lo
                                const sf_long *Super, const sf_long *SuperMap,
                                const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                                const sf_long *Lp, const sf_long *Li, const int32_t *owner, int rank, int nranks);
+/* ---- schedule inspection: what a rank WILL do, readable without running it.  sf_chol_plan_schedule_mapped /
+ * sf_lu_plan_schedule_mapped build rank `rank`'s plan exactly as sf_*_plan_create_mapped does but touch no device and allocate
+ * nothing (no GPU needed; the handle only serves the inspection calls below, "bytes_device" of sf_chol_plan_stat -- the bytes the
+ * real plan would allocate -- and sf_chol_plan_destroy; everything else returns SF_ERR_ARG).  With them all N plans of a
+ * factorization that needs N GPUs (BASELINE config 4: 256^3 over 8) can be checked against each other on a box with one GPU or
+ * none: same collective sequence inside every group, split launches partitioned exactly once, every top panel stored by exactly
+ * its group (tests/test_config4_schedules.py).  The reference has no counterpart (one host task queue, C:2267).
+ *   launch_info   out[10] = kind (0 potrf/getrf, 1 trsm, 2 in-block GEMM, 3 Schur GEMM, 4 outer GEMM, 5 fused step, 6 small Schur),
+ *                 tasks, divisible items (GEMM: stream-K units, kind 6: tiles), split (0/1), this rank's window [lo, hi) of the
+ *                 items, replicated-bit-identical (0/1), segment index (-1: the rank's own subtrees), index in group, group size
+ *   segment_info  out[6] = group mask, first launch, end launch, packed doubles of its all-reduce, early (issued one segment ahead
+ *                 on the second stream: 0/1), regions
+ *   panel_offsets xp[nsuper] = offset (doubles) of supernode s's panel on this rank, -1 = not stored here
+ *   solve_reduce_info  out[3] = group mask, first column, columns: the sums of the distributed forward sweep, in issue order */
+int sf_chol_plan_schedule_mapped(sf_chol_plan **plan, sf_long n, sf_long nsuper,
+                                 const sf_long *Super, const sf_long *SuperMap,
+                                 const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                                 const sf_long *Lp, const sf_long *Li, const int32_t *owner, int rank, int nranks);
+sf_long sf_chol_plan_num_launches(const sf_chol_plan *plan);
+int sf_chol_plan_launch_info(const sf_chol_plan *plan, sf_long k, sf_long *out10);
+int sf_chol_plan_segment_info(const sf_chol_plan *plan, sf_long k, sf_long *out6);
+int sf_chol_plan_panel_offsets(const sf_chol_plan *plan, sf_long *xp);
+sf_long sf_chol_plan_num_solve_reduces(const sf_chol_plan *plan);
+int sf_chol_plan_solve_reduce_info(const sf_chol_plan *plan, sf_long k, sf_long *out3);
 /* bit r set = rank r takes part in the all-reduce of segment k */
 uint32_t sf_chol_plan_segment_group(const sf_chol_plan *plan, sf_long k);
 sf_long sf_chol_plan_num_segments(const sf_chol_plan *plan);
@@ -252,6 +276,11 @@ int sf_lu_plan_create_mapped(sf_lu_plan **plan, int device, sf_long n, sf_long n
                              const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                              const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
                              const int32_t *owner, int rank, int nranks);
+int sf_lu_plan_schedule_mapped(sf_lu_plan **plan, sf_long n, sf_long nsuper,
+                               const sf_long *Super, const sf_long *SuperMap,
+                               const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                               const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
+                               const int32_t *owner, int rank, int nranks);   /* schedule-only, see sf_chol_plan_schedule_mapped */
 int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *Ux /* NULL if U aliases L */);
 /* Pivoting (BASELINE config 5 asks for it, the reference has none: magma_dgetrf_nopiv L:2653, devIpiv = NULL
  * L:3344, static pre-pivot L:589-673 disabled).  The symbolic structure is static, so rows can only be exchanged where that

@@ -136,6 +136,24 @@ lib.sf_chol_plan_create_mapped.restype = C.c_int
 lib.sf_lu_plan_create_mapped.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9 + \
     [C.POINTER(C.c_int32), C.c_int, C.c_int]
 lib.sf_lu_plan_create_mapped.restype = C.c_int
+lib.sf_chol_plan_schedule_mapped.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64] + [c_long_p] * 7 + \
+    [C.POINTER(C.c_int32), C.c_int, C.c_int]
+lib.sf_chol_plan_schedule_mapped.restype = C.c_int
+lib.sf_lu_plan_schedule_mapped.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64] + [c_long_p] * 9 + \
+    [C.POINTER(C.c_int32), C.c_int, C.c_int]
+lib.sf_lu_plan_schedule_mapped.restype = C.c_int
+lib.sf_chol_plan_num_launches.argtypes = [C.c_void_p]
+lib.sf_chol_plan_num_launches.restype = C.c_int64
+lib.sf_chol_plan_launch_info.argtypes = [C.c_void_p, C.c_int64, c_long_p]
+lib.sf_chol_plan_launch_info.restype = C.c_int
+lib.sf_chol_plan_segment_info.argtypes = [C.c_void_p, C.c_int64, c_long_p]
+lib.sf_chol_plan_segment_info.restype = C.c_int
+lib.sf_chol_plan_panel_offsets.argtypes = [C.c_void_p, c_long_p]
+lib.sf_chol_plan_panel_offsets.restype = C.c_int
+lib.sf_chol_plan_num_solve_reduces.argtypes = [C.c_void_p]
+lib.sf_chol_plan_num_solve_reduces.restype = C.c_int64
+lib.sf_chol_plan_solve_reduce_info.argtypes = [C.c_void_p, C.c_int64, c_long_p]
+lib.sf_chol_plan_solve_reduce_info.restype = C.c_int
 lib.sf_chol_plan_segment_group.argtypes = [C.c_void_p, C.c_int64]
 lib.sf_chol_plan_segment_group.restype = C.c_uint32
 lib.sf_chol_plan_num_segments.argtypes = [C.c_void_p]

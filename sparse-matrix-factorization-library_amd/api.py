@@ -281,6 +281,71 @@ class _ShardedPlanMixin:
         return lib.sf_chol_plan_factor_device_ptr(self._h)
 
 
+class _ScheduleMixin:
+    """schedule inspection (sf_chol_plan_launch_info & co.): works on real plans and on schedule-only ones"""
+
+    LAUNCH_FIELDS = ("kind", "tasks", "items", "split", "lo", "hi", "replicated", "segment", "group_index", "group_size")
+    SEGMENT_FIELDS = ("mask", "l0", "l1", "packed", "early", "regions")
+
+    def _table(self, count, fn, width):
+        out = np.zeros((max(count, 0), width), dtype=np.int64)
+        row = np.zeros(width, dtype=np.int64)
+        for k in range(count):
+            check(fn(self._h, k, _lp(row)), fn.__name__)
+            out[k] = row
+        return out
+
+    def launch_table(self):
+        """int64[launches, 10]: LAUNCH_FIELDS per launch, in issue order"""
+        return self._table(int(lib.sf_chol_plan_num_launches(self._h)), lib.sf_chol_plan_launch_info, 10)
+
+    def segment_table(self):
+        """int64[segments, 6]: SEGMENT_FIELDS per segment = per all-reduce of the factorization, in issue order"""
+        return self._table(int(lib.sf_chol_plan_num_segments(self._h)), lib.sf_chol_plan_segment_info, 6)
+
+    def solve_reduce_table(self):
+        """int64[reduces, 3]: (group mask, first column, columns) of the forward sweep's sums, in issue order"""
+        return self._table(int(lib.sf_chol_plan_num_solve_reduces(self._h)), lib.sf_chol_plan_solve_reduce_info, 3)
+
+    def panel_offsets(self, nsuper):
+        xp = np.zeros(max(nsuper, 1), dtype=np.int64)
+        check(lib.sf_chol_plan_panel_offsets(self._h, _lp(xp)), "sf_chol_plan_panel_offsets")
+        return xp[:nsuper]
+
+
+class Schedule(_ScheduleMixin, _ShardedPlanMixin):
+    """Rank `rank`'s plan of an nranks-way factorization WITHOUT a device (sf_chol_plan_schedule_mapped /
+    sf_lu_plan_schedule_mapped): the launch list, segments, storage map and byte counts of the real plan, nothing allocated."""
+
+    def __init__(self, sym, owner, rank, nranks, lu=False):
+        h = C.c_void_p()
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
+        if lu:
+            sym_in = bool(sym.symmetric)
+            self._keep += [None, None] if sym_in else [sym.Up, sym.Ui]
+            args = [_lp(a) if a is not None else None for a in self._keep]
+            check(lib.sf_lu_plan_schedule_mapped(C.byref(h), sym.n, sym.nsuper, *args,
+                                                 owner.ctypes.data_as(C.POINTER(C.c_int32)), int(rank), int(nranks)),
+                  "sf_lu_plan_schedule_mapped")
+        else:
+            check(lib.sf_chol_plan_schedule_mapped(C.byref(h), sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
+                                                   owner.ctypes.data_as(C.POINTER(C.c_int32)), int(rank), int(nranks)),
+                  "sf_chol_plan_schedule_mapped")
+        self._h, self.rank, self.nranks, self.nsuper = h, rank, nranks, sym.nsuper
+
+    def stat(self, name):
+        return float(lib.sf_chol_plan_stat(self._h, name.encode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sf_chol_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 class _ValidateMixin:
     def validate(self, return_x=False):
         """SparseFrame_validate on the device: b_i = 1 + i/n, solve, residual |Ax - b|_inf / (|A|_1 |x|_inf + |b|_inf)"""
@@ -290,7 +355,7 @@ class _ValidateMixin:
         return (res.value, x[:self.n]) if return_x else res.value
 
 
-class CholPlan(_ShardedPlanMixin, _ValidateMixin):
+class CholPlan(_ShardedPlanMixin, _ValidateMixin, _ScheduleMixin):
     """Device-resident supernodal Cholesky (flat ABI).  Raises if no HIP device is present.
     phase/load_top: multi-GPU sharding (sf_chol_plan_create_sharded); default = the whole matrix on one device.
     rank/nranks (with phase): distributed top (sf_chol_plan_create_distributed), run with factorize_phase(0) and then
@@ -372,7 +437,7 @@ class CholPlan(_ShardedPlanMixin, _ValidateMixin):
         self.close()
 
 
-class LUPlan(_ShardedPlanMixin, _ValidateMixin):
+class LUPlan(_ShardedPlanMixin, _ValidateMixin, _ScheduleMixin):
     """Device-resident supernodal no-pivot LU (flat ABI, sf_lu_plan_*).  `sym` comes from analyze(..., method='lu').
     phase/load_top/rank/nranks: distributed multi-GPU plan (sf_lu_plan_create_distributed), as CholPlan."""
 

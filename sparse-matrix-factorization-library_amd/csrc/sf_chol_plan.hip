@@ -68,6 +68,7 @@ size_t sf_reference_slot_size(int ndev, size_t min_mem) {
 
 int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
+    if (p->dry) { delete p; return SF_OK; }
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
@@ -114,7 +115,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                        const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
                        const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1,
-                       const uint32_t* top_mask = nullptr, const double* root_cum = nullptr) {
+                       const uint32_t* top_mask = nullptr, const double* root_cum = nullptr, bool dry = false) {
+    // dry: build the SCHEDULE only (launch list, segments, solve reduces, storage map, byte counts) -- no device is touched, nothing is
+    // allocated or uploaded, and the resulting plan can only be inspected (sf_chol_plan_launch_info & co.) and destroyed.  It is the
+    // same code path as a real plan up to the uploads, which is the point: what a rank WOULD do at a size or rank count this box cannot
+    // run (tests/test_config4_schedules.py walks all eight plans of 256^3 / 8 and checks them against each other).
     // root_cum (optional, nranks + 1 values from 0 to 1): the shares of the split launches of the sets that ALL ranks take part in
     // are [root_cum[r], root_cum[r + 1]) instead of equal ones -- create_mapped uses them to even out ranks whose other groups
     // differ in weight (an elimination tree the amalgamation made lopsided)
@@ -126,17 +131,20 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     if (nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks || (nranks > 1 && !phase_in)) return SF_ERR_ARG;
     if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
     if (n >= (sf_long)0x7fffffff) return SF_ERR_ARG;   // device row indices are 32-bit
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        fprintf(stderr, "[sparseframe-hip] no HIP device: the numeric factorization has no CPU fallback\n");
-        return SF_ERR_NO_DEVICE;
+    if (!dry) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+            fprintf(stderr, "[sparseframe-hip] no HIP device: the numeric factorization has no CPU fallback\n");
+            return SF_ERR_NO_DEVICE;
+        }
+        if (device < 0 || device >= ndev) return SF_ERR_ARG;
+        HIP_TRY(hipSetDevice(device));
     }
-    if (device < 0 || device >= ndev) return SF_ERR_ARG;
-    HIP_TRY(hipSetDevice(device));
 
     sf_chol_plan* p = new (std::nothrow) sf_chol_plan();
     if (!p) return SF_ERR_ALLOC;
-    p->device = device;
+    p->device = dry ? -1 : device;
+    p->dry = dry;
     p->lu = lu;
     p->rank = rank;
     p->nranks = nranks;
@@ -201,7 +209,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     const size_t xb_factor = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double);
     hipError_t factor_alloc_err = hipSuccess;
     double* factor_mem = nullptr;           // handed to the plan once everything else has succeeded; freed by the guard otherwise
-    std::thread factor_alloc([&factor_alloc_err, &factor_mem, xb_factor, device] {
+    std::thread factor_alloc([&factor_alloc_err, &factor_mem, xb_factor, device, dry] {
+        if (dry) return;
         factor_alloc_err = hipSetDevice(device);
         if (factor_alloc_err == hipSuccess) factor_alloc_err = hipMalloc((void**)&factor_mem, xb_factor);
     });
@@ -1018,6 +1027,17 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     }
 
     int rc = SF_OK;
+    // dry plans count the bytes a real plan would allocate and touch nothing
+    auto up = [&](auto** dptr, const auto& h) -> int {
+        if (!dry) return upload(dptr, h, &p->bytes_device);
+        *dptr = nullptr;
+        p->bytes_device += std::max<size_t>(h.size(), 1) * sizeof(typename std::decay_t<decltype(h)>::value_type);
+        return SF_OK;
+    };
+    auto dalloc = [&](void** ptr, size_t bytes) -> bool {
+        if (dry) { *ptr = nullptr; return true; }
+        return hipMalloc(ptr, bytes) == hipSuccess;
+    };
     do {
         // The plan's streams are HIGH-PRIORITY streams: the runtime multiplexes all streams of one priority over a few hardware
         // queues (4 by default), and the copy-back workers bring six streams of their own.  Whenever the compute stream landed on
@@ -1028,6 +1048,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         int prio_least = 0, prio_greatest = 0;
         bool prio = true;
         if (const char* env = sf_exp_env("SF_STREAM_PRIORITY")) prio = atoi(env) != 0;
+        if (dry) prio = false;
         if (prio && (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess || prio_greatest >= prio_least)) {
             (void)hipGetLastError();
             prio = false;
@@ -1037,89 +1058,91 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             (void)hipGetLastError();
             return hipStreamCreateWithFlags(st, flags) == hipSuccess;
         };
-        if (!new_stream(&p->stream, hipStreamDefault) || hipEventCreate(&p->ev0) != hipSuccess ||
+        if (!dry && (!new_stream(&p->stream, hipStreamDefault) || hipEventCreate(&p->ev0) != hipSuccess ||
             hipEventCreate(&p->ev1) != hipSuccess || hipEventCreate(&p->ev_s0) != hipSuccess ||
-            hipEventCreate(&p->ev_s1) != hipSuccess) { rc = SF_ERR_HIP; break; }
+            hipEventCreate(&p->ev_s1) != hipSuccess)) { rc = SF_ERR_HIP; break; }
         p->dl_events.assign(p->dl_ev_ready.size(), nullptr);
-        {
+        if (!dry) {
             bool ok = true;
             for (hipEvent_t& e : p->dl_events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;    // the copy workers sleep on them
             if (!ok) { rc = SF_ERR_HIP; break; }
         }
-        if ((rc = upload(&p->d_Lp, Lp64, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_Li, Li32, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_Super, Super32, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_SuperMap, SuperMap32, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_Lsip, Lsip64, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_Lsi, Lsi32, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_Lsxp, Lsxp64, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_potrf, potrf, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_trsm, trsm, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_steps, steps, &p->bytes_device))) break;
+        if ((rc = up(&p->d_Lp, Lp64))) break;
+        if ((rc = up(&p->d_Li, Li32))) break;
+        if ((rc = up(&p->d_Super, Super32))) break;
+        if ((rc = up(&p->d_SuperMap, SuperMap32))) break;
+        if ((rc = up(&p->d_Lsip, Lsip64))) break;
+        if ((rc = up(&p->d_Lsi, Lsi32))) break;
+        if ((rc = up(&p->d_Lsxp, Lsxp64))) break;
+        if ((rc = up(&p->d_potrf, potrf))) break;
+        if ((rc = up(&p->d_trsm, trsm))) break;
+        if ((rc = up(&p->d_steps, steps))) break;
         {
             std::vector<int> zeros(std::max<int32_t>(n_flags, 1), 0);
-            if ((rc = upload(&p->d_flags, zeros, &p->bytes_device))) break;
+            if ((rc = up(&p->d_flags, zeros))) break;
             const size_t tb = (size_t)std::max<int64_t>(max_diag_tasks, 1) * (lu ? 2048 : 1024) * sizeof(double);
-            if (hipMalloc((void**)&p->d_tinv, tb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            if (!dalloc((void**)&p->d_tinv, tb)) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += tb;
         }
-        if ((rc = upload(&p->d_probs, probs, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_gtasks, gtasks, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_stasks, stasks, &p->bytes_device))) break;
-        if ((rc = upload(&p->d_ktprefix, ktprefix, &p->bytes_device))) break;
+        if ((rc = up(&p->d_probs, probs))) break;
+        if ((rc = up(&p->d_gtasks, gtasks))) break;
+        if ((rc = up(&p->d_stasks, stasks))) break;
+        if ((rc = up(&p->d_ktprefix, ktprefix))) break;
         {   // relative maps of all Schur updates, built on the device (createRelativeMap, CK:42-60, once per plan)
             const size_t mb = (size_t)std::max<int64_t>(relmap_size, 1) * sizeof(int32_t);
-            if (hipMalloc((void**)&p->d_relmap, mb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            if (!dalloc((void**)&p->d_relmap, mb)) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += mb;
-            std::vector<GemmProb> firsts;
-            firsts.reserve(scatter_probs.size());
-            for (int64_t k : scatter_probs) firsts.push_back(probs[k]);
-            GemmProb* d_firsts = nullptr;
-            size_t dummy = 0;
-            if ((rc = upload(&d_firsts, firsts, &dummy))) break;
-            sf::launch_build_relmaps(d_firsts, (int)firsts.size(), p->d_Lsi, p->d_relmap, p->stream);
-            const hipError_t e1 = hipStreamSynchronize(p->stream), e2 = hipGetLastError();
-            (void)hipFree(d_firsts);
-            if (e1 != hipSuccess || e2 != hipSuccess) { rc = SF_ERR_HIP; break; }
+            if (!dry) {
+                std::vector<GemmProb> firsts;
+                firsts.reserve(scatter_probs.size());
+                for (int64_t k : scatter_probs) firsts.push_back(probs[k]);
+                GemmProb* d_firsts = nullptr;
+                size_t dummy = 0;
+                if ((rc = upload(&d_firsts, firsts, &dummy))) break;
+                sf::launch_build_relmaps(d_firsts, (int)firsts.size(), p->d_Lsi, p->d_relmap, p->stream);
+                const hipError_t e1 = hipStreamSynchronize(p->stream), e2 = hipGetLastError();
+                (void)hipFree(d_firsts);
+                if (e1 != hipSuccess || e2 != hipSuccess) { rc = SF_ERR_HIP; break; }
+            }
         }
         if (!solve.empty()) {
-            if ((rc = upload(&p->d_solve, solve, &p->bytes_device))) break;
+            if ((rc = up(&p->d_solve, solve))) break;
             if (!solveT_list.empty()) {
-                if ((rc = upload(&p->d_solveT_list, solveT_list, &p->bytes_device))) break;
-                if (hipMalloc((void**)&p->d_solveT, (size_t)solveT_size * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+                if ((rc = up(&p->d_solveT_list, solveT_list))) break;
+                if (!dalloc((void**)&p->d_solveT, (size_t)solveT_size * sizeof(double))) { rc = SF_ERR_ALLOC; break; }
                 p->bytes_device += (size_t)solveT_size * sizeof(double);
                 p->n_solveT = (int64_t)solveT_list.size();
             }
             // sync words of the solve: [0] status, then the flags / counters, then two launch tickets per step
             const size_t sb = (size_t)(1 + p->n_solve_sync + sf_chol_plan::SOLVE_TICKETS * p->solve_steps.size()) * sizeof(int);
-            if (hipMalloc((void**)&p->d_solve_sync, sb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            if (!dalloc((void**)&p->d_solve_sync, sb)) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += sb;
-            if (hipMalloc((void**)&p->d_x, std::max<int64_t>(n, 1) * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            if (!dalloc((void**)&p->d_x, std::max<int64_t>(n, 1) * sizeof(double))) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += std::max<int64_t>(n, 1) * sizeof(double);
         }
         if (lu || p->partial) {
-            if ((rc = upload(&p->d_Xp, XP, &p->bytes_device))) break;
+            if ((rc = up(&p->d_Xp, XP))) break;
         }
         if (!fill_tiles.empty()) {
             const size_t fb = fill_tiles.size() * sizeof(sf::FillTile);
-            if (hipMalloc(&p->d_fill, fb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
-            if (hipMemcpy(p->d_fill, fill_tiles.data(), fb, hipMemcpyHostToDevice) != hipSuccess) { rc = SF_ERR_HIP; break; }
+            if (!dalloc(&p->d_fill, fb)) { rc = SF_ERR_ALLOC; break; }
+            if (!dry && hipMemcpy(p->d_fill, fill_tiles.data(), fb, hipMemcpyHostToDevice) != hipSuccess) { rc = SF_ERR_HIP; break; }
             p->bytes_device += fb;
         }
         if (n_la_events > 0) {
-            bool ok = p->stream2 || new_stream(&p->stream2, hipStreamNonBlocking);
+            bool ok = dry || p->stream2 || new_stream(&p->stream2, hipStreamNonBlocking);
             p->la_events.assign((size_t)n_la_events, nullptr);
-            for (hipEvent_t& e : p->la_events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            for (hipEvent_t& e : p->la_events) ok = ok && (dry || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess);
             if (!ok) { rc = SF_ERR_HIP; break; }
         }
         if (!p->segments.empty()) {
             int64_t mx = 1;
             for (const Segment& sg : p->segments) mx = std::max(mx, sg.packed);
             p->scratch_elems = mx;
-            if (hipMalloc((void**)&p->d_scratch, 2 * mx * sizeof(double)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            if (!dalloc((void**)&p->d_scratch, 2 * mx * sizeof(double))) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += 2 * mx * sizeof(double);
-            bool ok = p->stream2 || new_stream(&p->stream2, hipStreamNonBlocking);
-            for (int k = 0; k < 2; ++k) {
+            bool ok = dry || p->stream2 || new_stream(&p->stream2, hipStreamNonBlocking);
+            for (int k = 0; k < 2 && !dry; ++k) {
                 ok = ok && hipEventCreateWithFlags(&p->ev_contrib[k], hipEventDisableTiming) == hipSuccess;
                 ok = ok && hipEventCreateWithFlags(&p->ev_reduced[k], hipEventDisableTiming) == hipSuccess;
                 ok = ok && hipEventCreateWithFlags(&p->ev_unpacked[k], hipEventDisableTiming) == hipSuccess;
@@ -1132,13 +1155,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             // or on the rank the caller names (load_top 0 / 1: the older interface, one group of all ranks)
             for (sf_long s = 0; s < nsuper; ++s)
                 mask[s] = (p->phase[s] == 0 || (p->phase[s] == 1 && (load_top == 2 ? group_idx(gmask[s]) == 0 : load_top != 0))) ? 1 : 0;
-            if ((rc = upload(&p->d_loadmask, mask, &p->bytes_device))) break;
+            if ((rc = up(&p->d_loadmask, mask))) break;
         }
         if (lu) {
             // pivot records: pivpos | pivinv, n entries each, + the perturbation counter; identity until a factorization with
             // pivoting overwrites the blocks it interchanges
             const size_t pb = (size_t)(2 * std::max<int64_t>(n, 1) + 1) * sizeof(int32_t);
-            if (hipMalloc((void**)&p->d_piv, pb) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+            if (!dalloc((void**)&p->d_piv, pb)) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += pb;
             if (const char* env = getenv("SF_LU_PIVOT_TOL")) {
                 p->piv_tol = std::min(1.0, std::max(0.0, atof(env)));
@@ -1146,10 +1169,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             }
             if (const char* env = getenv("SF_LU_PERTURB")) p->piv_perturb = std::max(0.0, atof(env));
             if (!p->u_alias) {
-                if ((rc = upload(&p->d_Up, Up64, &p->bytes_device))) break;
-                if ((rc = upload(&p->d_Ui, Ui32, &p->bytes_device))) break;
+                if ((rc = up(&p->d_Up, Up64))) break;
+                if ((rc = up(&p->d_Ui, Ui32))) break;
                 const size_t ub = std::max<int64_t>(p->unz, 1) * sizeof(double);
-                if (hipMalloc((void**)&p->d_Ux, ub) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+                if (!dalloc((void**)&p->d_Ux, ub)) { rc = SF_ERR_ALLOC; break; }
                 p->bytes_device += ub;
             }
         }
@@ -1162,8 +1185,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (factor_alloc_err != hipSuccess) { (void)hipGetLastError(); rc = SF_ERR_ALLOC; break; }
         p->d_Lsx = factor_mem;
         factor_mem = nullptr;
-        if (hipMalloc((void**)&p->d_Lx, vb) != hipSuccess ||
-            hipMalloc((void**)&p->d_info, (1 + p->n_tickets) * sizeof(int)) != hipSuccess) { rc = SF_ERR_ALLOC; break; }
+        if (!dalloc((void**)&p->d_Lx, vb) ||
+            !dalloc((void**)&p->d_info, (1 + p->n_tickets) * sizeof(int))) { rc = SF_ERR_ALLOC; break; }
         p->bytes_device += xb + vb + (1 + p->n_tickets) * sizeof(int);
     } while (0);
     if (rc) { sf_chol_plan_destroy(p); return rc; }
@@ -1203,7 +1226,7 @@ int sf_chol_plan_create_distributed(sf_chol_plan** out, int device, sf_long n, s
 static int create_mapped(sf_chol_plan** out, int device, bool lu, sf_long n, sf_long nsuper,
                          const sf_long* Super, const sf_long* SuperMap, const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                          const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
-                         const int32_t* owner, int rank, int nranks) {
+                         const int32_t* owner, int rank, int nranks, bool dry = false) {
     if (!out || !owner || nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks) return SF_ERR_ARG;
     if (nsuper < 0 || !Super || !Lsip || (nsuper > 0 && (!SuperMap || !Lsi))) return SF_ERR_ARG;
     std::vector<uint32_t> mask(std::max<sf_long>(nsuper, 1), 0);
@@ -1280,7 +1303,7 @@ static int create_mapped(sf_chol_plan** out, int device, bool lu, sf_long n, sf_
         }
     }
     return plan_create(out, device, lu, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, phase.data(), 2, rank, nranks, mask.data(),
-                       cum.empty() ? nullptr : cum.data());
+                       cum.empty() ? nullptr : cum.data(), dry);
 }
 
 int sf_chol_plan_create_mapped(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
@@ -1298,6 +1321,22 @@ int sf_lu_plan_create_mapped(sf_lu_plan** out, int device, sf_long n, sf_long ns
     return create_mapped(out, device, true, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, owner, rank, nranks);
 }
 
+// Schedule-only twins of the two calls above: no device, nothing allocated (plan_create's dry mode)
+int sf_chol_plan_schedule_mapped(sf_chol_plan** out, sf_long n, sf_long nsuper,
+                                 const sf_long* Super, const sf_long* SuperMap,
+                                 const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                                 const sf_long* Lp, const sf_long* Li, const int32_t* owner, int rank, int nranks) {
+    return create_mapped(out, -1, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, owner, rank, nranks, true);
+}
+
+int sf_lu_plan_schedule_mapped(sf_lu_plan** out, sf_long n, sf_long nsuper,
+                               const sf_long* Super, const sf_long* SuperMap,
+                               const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                               const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
+                               const int32_t* owner, int rank, int nranks) {
+    return create_mapped(out, -1, true, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, owner, rank, nranks, true);
+}
+
 // the group of ranks that sums segment k's block columns (bit r = rank r); 0 for a plan that is not distributed
 uint32_t sf_chol_plan_segment_group(const sf_chol_plan* p, sf_long k) {
     return (p && k >= 0 && k < (sf_long)p->segments.size()) ? p->segments[k].mask : 0u;
@@ -1312,6 +1351,7 @@ int sf_lu_plan_create(sf_lu_plan** out, int device, sf_long n, sf_long nsuper,
 
 int sf_chol_plan_set_values(sf_chol_plan* p, const sf_float* Lx) {
     if (!p || p->lu || (!Lx && p->nnz > 0)) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     if (p->nnz > 0) HIP_TRY(hipMemcpyAsync(p->d_Lx, Lx, p->nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1329,6 +1369,7 @@ int sf_lu_plan_create_distributed(sf_lu_plan** out, int device, sf_long n, sf_lo
 
 int sf_lu_plan_set_values(sf_lu_plan* p, const sf_float* Lx, const sf_float* Ux) {
     if (!p || !p->lu || (!Lx && p->nnz > 0) || (!p->u_alias && !Ux && p->unz > 0)) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     if (p->nnz > 0) HIP_TRY(hipMemcpyAsync(p->d_Lx, Lx, p->nnz * sizeof(double), hipMemcpyHostToDevice, p->stream));
     if (!p->u_alias && p->unz > 0) HIP_TRY(hipMemcpyAsync(p->d_Ux, Ux, p->unz * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -1345,6 +1386,7 @@ int sf_lu_plan_set_values(sf_lu_plan* p, const sf_float* Lx, const sf_float* Ux)
 
 int sf_chol_plan_sync(sf_chol_plan* p) {
     if (!p) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     int info = 0;
@@ -1385,9 +1427,20 @@ static hipError_t dl_publish(sf_chol_plan* p, size_t done) {
     return hipSuccess;
 }
 
+// This rank's window [lo, hi) of a launch's `total` divisible items (GEMM launches: stream-K units; k_update_small: tiles); all of
+// them unless the launch is split over a group.  The boundaries are the same doubles on the two ranks they separate, so the windows
+// of a group's members tile [0, total) exactly (checked for every launch of 256^3 / 8 by tests/test_config4_schedules.py).
+static inline void launch_window(const Launch& L, int64_t total, int64_t* lo, int64_t* hi) {
+    *lo = 0; *hi = total;
+    if (!L.split) return;
+    *lo = (int64_t)((double)total * L.share_lo);
+    *hi = L.share_hi >= 1.0 ? total : (int64_t)((double)total * L.share_hi);
+}
+
 // launches [l0, l1); first: start of a factorization (timer, memset, assembly); last: its end (timer, status)
 static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool last, int sync) {
     if (!p->values_set) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
     struct EventList {      // profiling events; destroyed on every exit path
@@ -1451,8 +1504,8 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, pc.pivinv, st); break;
             case 6: {       // k_update_small; a split launch (distributed top): this rank's share of the tiles (the update is a sum)
-                int64_t lo = 0, hi = L.count;
-                if (L.split) { lo = (int64_t)((double)L.count * L.share_lo); hi = L.share_hi >= 1.0 ? L.count : (int64_t)((double)L.count * L.share_hi); }
+                int64_t lo, hi;
+                launch_window(L, L.count, &lo, &hi);
                 sf::launch_update_small(p->d_probs, p->d_stasks + L.first + lo, (int)(hi - lo), p->d_Lsx, p->d_relmap, st);
                 break;
             }
@@ -1463,12 +1516,9 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             case 2:
             case 3:
             case 4: {
-                uint32_t u0 = 0, u1 = L.units;
-                if (L.split) {
-                    // the boundaries are the same doubles on the two ranks they separate: the windows tile [0, units) exactly
-                    u0 = (uint32_t)((double)L.units * L.share_lo);
-                    u1 = L.share_hi >= 1.0 ? L.units : (uint32_t)((double)L.units * L.share_hi);
-                }
+                int64_t w0, w1;
+                launch_window(L, L.units, &w0, &w1);
+                const uint32_t u0 = (uint32_t)w0, u1 = (uint32_t)w1;
                 sf::launch_gemm(p->d_probs, p->d_gtasks + L.first, p->d_ktprefix + L.prefix_first, L.count, u0, u1,
                                 L.kind == 3 ? 1 : 0, p->d_Lsx, p->d_relmap, p->gemm_dynamic ? p->d_info + 1 + L.ticket : nullptr, st,
                                 (L.whole_tiles && !L.split) ? 1 : 0, (L.lane == 1 && !p->profiling) ? p->la_grid : 0);
@@ -1524,6 +1574,49 @@ int sf_chol_plan_factorize_phase(sf_chol_plan* p, int which, int sync) {
 
 sf_long sf_chol_plan_num_segments(const sf_chol_plan* p) { return p ? (sf_long)p->segments.size() : 0; }
 
+// ---- schedule inspection (real and schedule-only plans; tests/test_config4_schedules.py, tools/) ----
+sf_long sf_chol_plan_num_launches(const sf_chol_plan* p) { return p ? (sf_long)p->launches.size() : 0; }
+
+int sf_chol_plan_launch_info(const sf_chol_plan* p, sf_long k, sf_long* out) {
+    if (!p || !out || k < 0 || k >= (sf_long)p->launches.size()) return SF_ERR_ARG;
+    const Launch& L = p->launches[(size_t)k];
+    const bool gemm = L.kind >= 2 && L.kind <= 4;
+    const int64_t total = gemm ? (int64_t)L.units : (int64_t)L.count;
+    int64_t lo, hi;
+    launch_window(L, total, &lo, &hi);
+    sf_long seg = -1;
+    if ((size_t)k >= p->launch_split && !p->segments.empty()) {
+        size_t a = 0, b = p->segments.size();       // last segment with l0 <= k
+        while (b - a > 1) { const size_t m = (a + b) / 2; if (p->segments[m].l0 <= (size_t)k) a = m; else b = m; }
+        if (p->segments[a].l0 <= (size_t)k && (size_t)k < p->segments[a].l1) seg = (sf_long)a;
+    }
+    out[0] = L.kind; out[1] = L.count; out[2] = total; out[3] = L.split ? 1 : 0; out[4] = lo; out[5] = hi;
+    out[6] = (L.whole_tiles && !L.split) ? 1 : 0; out[7] = seg; out[8] = L.share_idx; out[9] = L.share_cnt;
+    return SF_OK;
+}
+
+int sf_chol_plan_segment_info(const sf_chol_plan* p, sf_long k, sf_long* out) {
+    if (!p || !out || k < 0 || k >= (sf_long)p->segments.size()) return SF_ERR_ARG;
+    const Segment& sg = p->segments[(size_t)k];
+    out[0] = (sf_long)sg.mask; out[1] = (sf_long)sg.l0; out[2] = (sf_long)sg.l1; out[3] = sg.packed; out[4] = sg.early ? 1 : 0;
+    out[5] = (sf_long)sg.off.size();
+    return SF_OK;
+}
+
+int sf_chol_plan_panel_offsets(const sf_chol_plan* p, sf_long* xp) {
+    if (!p || (!xp && p->nsuper > 0)) return SF_ERR_ARG;
+    for (int64_t s = 0; s < p->nsuper; ++s) xp[s] = p->h_XP[(size_t)s];
+    return SF_OK;
+}
+
+sf_long sf_chol_plan_num_solve_reduces(const sf_chol_plan* p) { return p ? (sf_long)p->solve_reduces.size() : 0; }
+
+int sf_chol_plan_solve_reduce_info(const sf_chol_plan* p, sf_long k, sf_long* out) {
+    if (!p || !out || k < 0 || k >= (sf_long)p->solve_reduces.size()) return SF_ERR_ARG;
+    out[0] = (sf_long)p->solve_reduces[(size_t)k].mask; out[1] = p->solve_reduces[(size_t)k].off; out[2] = p->solve_reduces[(size_t)k].cnt;
+    return SF_OK;
+}
+
 int sf_chol_plan_segment_regions(const sf_chol_plan* p, sf_long k, sf_long capacity, sf_long* nregions, sf_long* offsets, sf_long* counts) {
     if (!p || k < 0 || k >= (sf_long)p->segments.size() || !nregions) return SF_ERR_ARG;
     const Segment& sg = p->segments[k];
@@ -1555,6 +1648,7 @@ static int seg_copy(sf_chol_plan* p, const Segment& sg, double* buf, bool pack, 
 int sf_chol_plan_segment_pack(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count) {
     if (!p || k < 0 || k >= (sf_long)p->segments.size() || !dptr || !count) return SF_ERR_ARG;
     if (p->packed_pending >= 0) return SF_ERR_ARG;           // the previous packed segment has not been run
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     const Segment& sg = p->segments[k];
     double* buf = p->d_scratch + (k & 1) * p->scratch_elems;
@@ -1571,6 +1665,7 @@ int sf_chol_plan_factorize_segment(sf_chol_plan* p, sf_long k, int sync) {
     const Segment& sg = p->segments[k];
     if (p->packed_pending >= 0) {
         if (p->packed_pending != k) return SF_ERR_ARG;
+        if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
         HIP_TRY(hipSetDevice(p->device));
         int rc = seg_copy(p, sg, p->d_scratch + (k & 1) * p->scratch_elems, false, p->stream);
         if (rc) return rc;
@@ -1634,6 +1729,7 @@ int sf_plan_import_from(sf_chol_plan* dst, sf_chol_plan* const* parts, int npart
 // finish: the main stream waits for it, scatters the sums back and runs the segment's launches.
 int sf_seg_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count) {
     if (!p || k < 0 || k >= (sf_long)p->segments.size() || !dptr || !count || !p->stream2) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     const int h = (int)(k & 1);
     HIP_TRY(hipEventRecord(p->ev_contrib[h], p->stream));
@@ -1649,12 +1745,14 @@ int sf_seg_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count) {
 }
 void* sf_plan_stream2(sf_chol_plan* p) { return p ? (void*)p->stream2 : nullptr; }
 int sf_seg_reduced(sf_chol_plan* p, sf_long k) {
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventRecord(p->ev_reduced[k & 1], p->stream2));
     return SF_OK;
 }
 int sf_seg_finish(sf_chol_plan* p, sf_long k) {
     if (!p || k < 0 || k >= (sf_long)p->segments.size()) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     const int h = (int)(k & 1);
     const Segment& sg = p->segments[k];
@@ -1671,6 +1769,7 @@ extern "C" {
 
 int sf_chol_plan_set_stream(sf_chol_plan* p, void* stream) {
     if (!p) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->stream && p->own_stream) HIP_TRY(hipStreamDestroy(p->stream));
@@ -1690,6 +1789,7 @@ int sf_chol_plan_validate(sf_chol_plan* p, sf_float* residual, sf_float* x_host)
     if (p->partial || (p->nsuper > 0 && !p->d_solve) || !p->values_set) return SF_ERR_ARG;
     *residual = 0.0;
     if (p->n <= 0) return SF_OK;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     if (!p->d_resid) {
         HIP_TRY(hipMalloc((void**)&p->d_resid, (3 * (size_t)p->n + 4) * sizeof(double)));
@@ -1926,6 +2026,7 @@ static void dl_worker(sf_chol_plan* p, int w) {
 
 int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     if (!p || !host_out || p->dl_active) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     if (p->dl_cpus_known == 0) dl_lookup_cpus(p);
     if (!p->h_ring) {
@@ -2021,6 +2122,7 @@ int sf_chol_plan_top_region(sf_chol_plan* p, void** dptr, sf_long* count) {
 
 int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
     if (!p || (!Lsx && p->xsize > 0)) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->xsize <= 0) return SF_OK;
@@ -2063,6 +2165,7 @@ int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
 int sf_chol_plan_get_factor_range(sf_chol_plan* p, sf_long e_begin, sf_long e_end, sf_float* out) {
     if (!p || p->partial || e_begin < 0 || e_end > p->xsize || e_end < e_begin || (!out && e_end > e_begin)) return SF_ERR_ARG;
     if (e_end == e_begin) return SF_OK;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     if (!p->lu) {
         HIP_TRY(hipMemcpyAsync(out, p->d_Lsx + e_begin, (e_end - e_begin) * sizeof(double), hipMemcpyDeviceToHost, p->stream));
@@ -2082,6 +2185,7 @@ int sf_chol_plan_get_factor_range(sf_chol_plan* p, sf_long e_begin, sf_long e_en
 int sf_plan_panel_hashes(sf_chol_plan* p, const uint64_t** out) {
     if (!p || !out) return SF_ERR_ARG;
     if (p->hash_epoch != p->epoch || p->h_hash.size() != (size_t)std::max<int64_t>(p->nsuper, 1)) {
+        if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
         HIP_TRY(hipSetDevice(p->device));
         const size_t nb = (size_t)std::max<int64_t>(p->nsuper, 1) * sizeof(unsigned long long);
         unsigned long long* d_h = nullptr;
@@ -2113,6 +2217,7 @@ int sf_lu_plan_set_pivoting(sf_lu_plan* p, double tol, double perturb) {
 // block; the identity where nothing moved, for panels not stored on this rank (left untouched) and when pivoting is off
 int sf_lu_plan_get_pivots(sf_lu_plan* p, sf_long* pivpos) {
     if (!p || !p->lu || (!pivpos && p->n > 0)) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (!(p->piv_tol > 0.0)) {
@@ -2218,6 +2323,7 @@ int sf_chol_plan_solve(sf_chol_plan* p, const sf_float* b_host, sf_float* x_host
     if (p->partial || (p->nsuper > 0 && !p->d_solve)) return SF_ERR_ARG;
     const double* fwd_base = p->d_Lsx;
     const double* bwd_base = p->lu ? p->d_Lsx + p->xC : p->d_Lsx;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
     if (p->n <= 0) return SF_OK;

@@ -365,6 +365,7 @@ int sf_chol_plan_prepare_comm(sf_chol_plan* p, sf_comm* comm) {
     if (!p || !comm || comm->nranks != p->nranks || comm->rank != p->rank) return SF_ERR_ARG;
     int rc = sf_comm_prepare_groups(comm, p->all_masks.data(), (int)p->all_masks.size());
     if (rc) return rc;
+    if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
     HIP_TRY(hipSetDevice(p->device));
     double* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, sizeof(double)));

@@ -149,6 +149,7 @@ struct sf_chol_plan {
     double piv_tol = 0.0, piv_perturb = 0.0, amax = 0;
     int32_t* d_piv = nullptr;   // pivpos[n] | pivinv[n] | perturbation counter
     int last_perturbed = 0;
+    bool dry = false;           // schedule-only plan (plan_create's dry mode): no device resources, inspection only
     bool lu = false;            // no-pivot LU: every supernode has an L panel and a U^T panel (see plan_create)
     int64_t xC = 0;             // doubles in one set of nsrow x nscol panels (Cholesky: == xsize)
     int64_t unz = 0;            // LU: entries of U (by row)

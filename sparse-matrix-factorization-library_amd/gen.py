@@ -23,20 +23,27 @@ def laplacian_lower(nx, ny=1, nz=1, diag=None):
     dims = (nx > 1) + (ny > 1) + (nz > 1)
     if diag is None:
         diag = 2.0 * max(dims, 1)
+    # built column by column without a sort (a stable sort of 6.7e7 entries is most of the 28 s the COO route took at 256^3):
+    # column j holds its diagonal, then j+1, j+nx, j+nx*ny where they exist -- the order the stable counting sort of the
+    # reference's compress step (SparseFrame.c:560-576) gives the same entries listed stencil arm by stencil arm
     idx = np.arange(n, dtype=np.int64)
     x = idx % nx
     y = (idx // nx) % ny
-    z = idx // (nx * ny)
-    rows = [idx]
-    cols = [idx]
-    vals = [np.full(n, float(diag))]
-    for mask, off in ((x + 1 < nx, 1), (y + 1 < ny, nx), (z + 1 < nz, nx * ny)):
-        j = idx[mask]
-        rows.append(j + off)     # row > col: lower triangle
-        cols.append(j)
-        vals.append(np.full(j.size, -1.0))
-    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
-    Cp, Ci, Cx = _csc_from_coo(n, rows, cols, vals)
+    m1 = x + 1 < nx
+    m2 = y + 1 < ny
+    m3 = idx < n - nx * ny if nz > 1 else np.zeros(n, dtype=bool)
+    del x, y
+    Cp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(1 + m1.astype(np.int64) + m2 + m3, out=Cp[1:])
+    Ci = np.empty(Cp[-1], dtype=np.int64)
+    Cx = np.full(Cp[-1], -1.0)
+    pos = Cp[:-1].copy()
+    Ci[pos] = idx
+    Cx[pos] = float(diag)
+    for mask, off in ((m1, 1), (m2, nx), (m3, nx * ny)):
+        pos += 1
+        Ci[pos[mask]] = idx[mask] + off
+        pos[~mask] -= 1
     return n, Cp, Ci, Cx
 
 

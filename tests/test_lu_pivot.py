@@ -238,14 +238,26 @@ def test_pivot_sequence_and_factor_match_the_oracle(oracle, monkeypatch, case, f
     assert int(plan.stat("perturbed_pivots")) == nper
     Lsx = plan.get_factor()
     assert rel_err(Lsx, ref) <= vtol, (name, rel_err(Lsx, ref))
-    # the device solve (interchanges applied block by block in the forward sweep) against the oracle's solve with ITS factor
+    # The device solve (interchanges applied block by block in the forward sweep) against the oracle's solve applied to THE DEVICE'S OWN
+    # factor and pivots: same inputs, so the comparison isolates the solve from the factor's conditioning.  What remains is the
+    # rounding of two summation orders, which a triangular solve amplifies by its own condition number: the yardstick is measured
+    # here, not assumed -- the spread of the ORACLE's solution when every entry of that factor moves by one ulp at random.  CPU
+    # measurements of that spread: dense_64 2e-15, dense_200 1e-13, dense_700 7e-13, general 3e-13, zero_diag_12 7e-12, zero_diag_16
+    # 1.0-1.6e-10 (multipliers of 2e6 next to the zeroed entries: there 1e-12 is below what ONE ulp in the factor does, whatever the
+    # solver).  Bound: 1e-12, or 4 x that spread where the spread is larger.
     b = 1.0 + np.arange(n) / n
     x = plan.solve(b)
-    want = oracle.lu_solve_pivot(S, ref, pivpos, b)
-    # (zero_diag_16: pivots of 1e-6 next to the zeroed entries make the SOLUTION sensitive to the last bits of the factor -- 1e6 x the
-    # factor's 1e-12; the factor itself and the pivot sequence are compared above)
-    xtol = 1e-6 if name == "zero_diag_16" else max(vtol, 1e-11) * 1e2
-    assert np.max(np.abs(x - want)) <= xtol * np.abs(want).max(), name
+    want = oracle.lu_solve_pivot(S, Lsx, got_piv, b)
+    rng = np.random.default_rng(5)
+    spread = 0.0
+    for _ in range(3):
+        moved = Lsx * (1.0 + rng.integers(-1, 2, Lsx.size) * 1.1102230246251565e-16)
+        spread = max(spread, float(np.max(np.abs(oracle.lu_solve_pivot(S, moved, got_piv, b) - want)) / np.abs(want).max()))
+    err = float(np.max(np.abs(x - want)) / np.abs(want).max())
+    assert err <= max(1e-12, 4.0 * spread), (name, err, spread)
+    # ... and against the oracle's solve with the ORACLE's factor (factor conditioning included): the looser end-to-end statement
+    want_ref = oracle.lu_solve_pivot(S, ref, pivpos, b)
+    assert np.max(np.abs(x - want_ref)) <= max(vtol, 1e-11) * 1e2 * max(1.0, spread / 1e-12) * np.abs(want_ref).max(), name
     plan.close()
 
 
