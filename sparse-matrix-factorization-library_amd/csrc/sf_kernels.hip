@@ -207,6 +207,36 @@ __device__ __forceinline__ void getrf_panel_wave(double (&a)[W], int lane, int J
     }
 }
 
+// NATURAL-PIVOT FAST PATH of getrf_panel_wave (k_step<true>): the same W columns eliminated with the natural rows as pivots -- the
+// arithmetic of the general path when every natural pivot passes, instruction for instruction (same reciprocal, same fused
+// multiply-adds: bit-identical results) -- as STRAIGHT-LINE code: the threshold test of column j (does a free row have
+// tol * |a_ij| > |a_jj|?  is the pivot zero, NaN, or below the perturbation threshold?) only accumulates into a wave-uniform mask
+// instead of steering a branch, so nothing on the column's critical path waits for a vector compare to reach the scalar unit and
+// the compiler schedules the 16 columns as one block (the general form's per-column branches cost it a copy of all 16 registers per
+// column and 48 spilled SGPRs; profiles/r03_k_step_stamps.txt: 5.9 us per 16-column panel against 2.4 us for Cholesky's).
+// Valid while every earlier pivot of the block was natural too (lanes < J0 used, lanes >= J0 free).  Returns false when some
+// natural pivot does NOT pass: the caller then reloads the panel and runs getrf_panel_wave on it (a[] is garbage in that case).
+template <int W>
+__device__ __forceinline__ bool getrf_panel_natural(double (&a)[W], int lane, int J0, int b, double tol, double eps) {
+    unsigned long long viol = 0ull;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int J = J0 + j;
+        const double piv = readlane_dyn_f64(a[j], J);
+        const bool below = lane > J;
+        viol |= __ballot(below && !(tol * fabs(a[j]) <= fabs(piv)));            // a NaN entry counts as larger
+        if (J < b && (!(fabs(piv) >= eps) || piv == 0.0)) viol |= 1ull;           // zero, NaN or tiny pivot (wave-uniform test)
+        double rp = __builtin_amdgcn_rcp(piv);
+        rp = rp * (2.0 - piv * rp);
+        rp = rp * (2.0 - piv * rp);
+        const double l = below ? a[j] * rp : 0.0;
+        if (below) a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < W; ++c) a[c] -= l * readlane_dyn_f64(a[c], J);
+    }
+    return viol == 0ull;
+}
+
 // The block lives in two panels: D(r,c), c < r (L, unit diagonal implied) in the L panel at (diag+r, diag+c); D(r,c), c >= r
 // (U) in the U^T panel at (diag+c, diag+r).
 template <int W>
@@ -1276,7 +1306,7 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 // The updated 64 x 64 tile then goes to LDS (U[column][row]) where the POTRF wave / the blocked solve picks it up.
 // ---------------------------------------------------------------------------------------------------
 #ifndef SF_LU_STEP_WGS
-#define SF_LU_STEP_WGS 2      // workgroups per CU the LU variant of k_step is compiled for (experiment knob)
+#define SF_LU_STEP_WGS 3      // workgroups per CU the LU variant of k_step is compiled for (168 VGPRs; the throughput-bound launches of the lower levels want the third)
 #endif
 constexpr int ST_ULD = ST_ROWS + 1;      // LDS column stride of the updated tile U[c][r]
 constexpr int ST_KC = 32;                // K chunk of the update's LDS-staged operand
@@ -1443,7 +1473,46 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     }
     // accumulators -> U[cj][ci] = A(ci, cj) - update (padded with the identity / zeros); the staging buffers are dead
     // (the chunk loop ends with a barrier)
-    if (is_diag) {
+    if (LU && is_diag) {
+        // LU diagonal task: the 64 x 64 block lives in two panels -- D(ci,cj), cj < ci in the L panel, the rest transposed in the U^T
+        // panel.  Both halves are read column by column (L) and row by row (U^T) with the lane along the panels' contiguous
+        // direction: 32 fully coalesced loads per thread in flight, then the image U[cj][ci] = D(ci, cj) (identity padding beyond
+        // b), then the update (the last 64 columns' contribution, in the accumulator layout) subtracted in LDS.  (The first form
+        // read the U half in the accumulator layout -- 64 cache lines per load instruction: 3.4 us from entry to the first panel
+        // against 2.6 now, profiles/r04_*_step_stamps.txt.  Requested BEFORE the update's K loop the loads overlap it, but their 64
+        // registers stay live through the loop for every task of the launch: 247 VGPRs, 2 workgroups per CU instead of 3, and the
+        // throughput-bound launches of the lower levels lose more than the diagonal workgroup gains.)
+        {
+            // (one half at a time: 32 VGPRs each; both in flight at once pushed the kernel past 168 VGPRs = 3 workgroups per CU)
+            const int lc = min(lane, b - 1);
+            double blk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) blk[i] = Ag[lc + (int64_t)min(16 * wave + i, b - 1) * ld];     // D(lane, k): column k below its diagonal
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = 16 * wave + i;
+                if (lane > k) U[k * ST_ULD + lane] = (lane < b && k < b) ? blk[i] : 0.0;                // (ci = lane, cj = k)
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) blk[i] = Dg[lc + (int64_t)min(16 * wave + i, b - 1) * ld];     // D(k, lane) = PU(lane, k): row k from its diagonal on
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = 16 * wave + i;
+                if (lane >= k) U[lane * ST_ULD + k] = (lane < b && k < b) ? blk[i] : ((lane == k) ? 1.0 : 0.0);    // (ci = k, cj = lane)
+            }
+        }
+        if (nhp > 0) {
+            __syncthreads();
+            const int ci = 16 * wave + fr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cj = 16 * q + fk + 4 * r;
+                    if (ci < b && cj < b) U[cj * ST_ULD + ci] -= acc[q][r];
+                }
+        }
+    } else if (is_diag) {
         const int ci = 16 * wave + fr;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -1453,15 +1522,9 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 // loads are unconditional (clamped addresses) and selected afterwards: a load under a per-element
                 // condition costs a branch and its own wait, i.e. 16 dependent round trips per lane
                 const int cic = min(ci, nrows - 1), cjc = min(cj, b - 1);
-                double v = (is_diag && ci == cj) ? 1.0 : 0.0;
-                if (LU && is_diag) {
-                    // the full block: D(ci,cj) lives in the L panel for cj < ci, in the U^T panel (transposed) otherwise
-                    const double dl = Ag[cic + (int64_t)cjc * ld], du = Dg[cjc + (int64_t)cic * ld];
-                    if (ci < b && cj < b) v = ((cj < ci) ? dl : du) - acc[q][r];
-                } else {
-                    const double av = Ag[cic + (int64_t)cjc * ld];
-                    if (ci < nrows && cj < b && (!is_diag || cj <= ci)) v = av - acc[q][r];
-                }
+                double v = (ci == cj) ? 1.0 : 0.0;
+                const double av = Ag[cic + (int64_t)cjc * ld];
+                if (ci < nrows && cj < b && cj <= ci) v = av - acc[q][r];
                 U[cj * ST_ULD + ci] = v;
             }
     }
@@ -1478,11 +1541,12 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         // The unblocked form (a 64-value row per lane in getrf_panel_wave<true, 64>, 4,000 v_readlane pairs on the critical path) cost 68 us per
         // step and 256 VGPRs; see DESIGN 6b for the figures of this one.
         __shared__ int s_piv[NB], s_pos[NB];
-        if (tid < NB) s_pos[tid] = -1;
+        if (tid < NB) { s_pos[tid] = -1; s_piv[tid] = tid; }
         __syncthreads();
         ST_STAMP(2);
         bool bad = false, active = lane < b;
         int np = 0, pos = lane;
+        bool nat_all = true;        // wave 0: every pivot so far was the natural row (wave-uniform)
 #pragma unroll 1
         for (int q = 0; q < NB / 16; ++q) {
             const int c0 = 16 * q;
@@ -1490,7 +1554,21 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 double a[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) a[u] = U[(c0 + u) * ST_ULD + lane];
-                getrf_panel_wave<true, 16>(a, lane, c0, b, pc.tol, pc.eps, bad, np, pos, active, s_piv);
+                // natural pivots first (straight-line code, see getrf_panel_natural); the general search only when one of them fails
+                bool done = false;
+                if (nat_all) {
+                    done = getrf_panel_natural<16>(a, lane, c0, b, pc.tol, pc.eps);
+                    if (done) {
+                        if (lane >= c0 && lane < c0 + 16) { active = false; s_piv[lane] = lane; }       // pos stays = lane
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) a[u] = U[(c0 + u) * ST_ULD + lane];
+                    }
+                }
+                if (!done) {
+                    nat_all = false;
+                    getrf_panel_wave<true, 16>(a, lane, c0, b, pc.tol, pc.eps, bad, np, pos, active, s_piv);
+                }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) U[(c0 + u) * ST_ULD + lane] = a[u];
                 s_pos[lane] = active ? -1 : pos;
@@ -1550,48 +1628,61 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         }
         __syncthreads();
         {
-            // rows go to their pivot positions: wave w moves the columns 16 w .. 16 w + 15 (its reads precede its writes, and no
-            // other wave touches these columns), L part to the L panel, U part (transposed) to the U^T panel
-            const int mypos = s_pos[lane];
+            // The factored block goes to the two panels, rows at their pivot positions, every store instruction along a panel's
+            // contiguous direction.  L part: wave w takes the columns 16 w .. 16 w + 15, lane = row POSITION (its values come from
+            // the row s_piv[position] of the LDS image); with interchanges the image itself is brought into pivot order on the way
+            // (a wave's reads of a column precede its writes, no other wave touches these columns).  U part: from the ordered image,
+            // wave w takes the rows 16 w .. 16 w + 15, lane = column.  (Stored in the accumulator-like layout, the first form issued
+            // 64 cache lines per store instruction for the U half: 2.0 us + a longer drain before the flag.)
+            const int src = s_piv[lane];                     // the row that ended at position `lane`
+            const bool moved = !__all(src == lane);         // same answer in every wave (one pivot list)
             double* __restrict__ PUd = Lsx + t.xpanel + t.diag + (int64_t)t.diag * ld;
             double a[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a[u] = U[(16 * wave + u) * ST_ULD + lane];
+            for (int u = 0; u < 16; ++u) a[u] = U[(16 * wave + u) * ST_ULD + src];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int c = 16 * wave + u;
-                if (lane < b && c < b) {
-                    if (c < mypos) Ag[mypos + (int64_t)c * ld] = a[u]; else PUd[c + (int64_t)mypos * ld] = a[u];
-                }
-                U[c * ST_ULD + mypos] = a[u];       // the factored block (L below, U on and above the diagonal; identity padding)
+                if (lane < b && c < lane) Ag[lane + (int64_t)c * ld] = a[u];
+                if (moved) U[c * ST_ULD + lane] = a[u];
+            }
+            if (moved) __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = 16 * wave + u;
+                const double v = U[lane * ST_ULD + r];
+                if (lane < b && r <= lane) PUd[lane + (int64_t)r * ld] = v;
             }
         }
-        __syncthreads();
         ST_STAMP(7);
         {
             // inverses of the 16 x 16 diagonal sub-blocks the row tasks solve against: of U11^T (lower, for the L rows) at
-            // tinv[slot][0][w], of the unit-lower L11 (for the U^T rows) at tinv[slot][1][w]; wave w does block w of both
+            // tinv[slot][0][w], of the unit-lower L11 (for the U^T rows) at tinv[slot][1][w]; wave w does block w of both -- the two
+            // sets side by side in ONE substitution: lanes 0..15 hold the columns of the first, lanes 16..31 of the second (the
+            // matrix entry a step multiplies by is an LDS broadcast per set: two addresses per read), lanes 32..63 repeat them.
+            // (One set after the other in every lane, the first form, was 3.3 us of the diagonal workgroup's 40; Cholesky's one set 2.0.)
             const int o = 16 * wave, j = lane & 15;
-            double wu[16], wl[16];
+            const bool lset = (lane & 16) != 0;
+            // entry (r, c) of the set's matrix: U11^T(r,c) = U11(c,r) = row o+c, column o+r of the block (U[column][row] image:
+            // offset r * ULD + c); L11(r,c) = row o+r, column o+c (offset c * ULD + r) -- per-lane strides, ONE read per step
+            const int sr = lset ? 1 : ST_ULD, sc = lset ? ST_ULD : 1;
+            const double* __restrict__ Ub = U + o * ST_ULD + o;
+            double w[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                double su = (r == j) ? 1.0 : 0.0, sl = su;
+                double sacc = (r == j) ? 1.0 : 0.0;
 #pragma unroll
-                for (int c = 0; c < r; ++c) {
-                    su -= U[(o + r) * ST_ULD + o + c] * wu[c];      // U11^T(r,c) = U11(c,r): row o+c, column o+r of the block
-                    sl -= U[(o + c) * ST_ULD + o + r] * wl[c];      // L11(r,c): row o+r, column o+c
-                }
-                const double trr = U[(o + r) * ST_ULD + o + r];
+                for (int c = 0; c < r; ++c) sacc -= Ub[r * sr + c * sc] * w[c];
+                const double trr = Ub[r * (ST_ULD + 1)];
                 double rp = __builtin_amdgcn_rcp(trr);
                 rp = rp * (2.0 - trr * rp);
                 rp = rp * (2.0 - trr * rp);
-                wu[r] = su * rp;
-                wl[r] = sl;
+                w[r] = lset ? sacc : sacc * rp;
             }
-            double* __restrict__ out = tinv + (int64_t)t.slot * 2048 + wave * 256 + j * 16;
-            if (lane < 16) {
+            double* __restrict__ out = tinv + (int64_t)t.slot * 2048 + (lset ? 1024 : 0) + wave * 256 + j * 16;
+            if (lane < 32) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { out[r] = wu[r]; out[1024 + r] = wl[r]; }
+                for (int r = 0; r < 16; ++r) out[r] = w[r];
             }
         }
         ST_STAMP(8);

@@ -87,6 +87,21 @@ def test_golden_fixtures():
         plan.close()
 
 
+@pytest.mark.parametrize("name", ["chol_lap3d_24", "chol_stencil2d_200"])
+def test_golden_fixtures_large(name, monkeypatch):
+    """tests/golden/large_sampled.json (make_golden_large.py: oracle output accepted there only after agreeing with dense LAPACK /
+    SuperLU): an 895-column root panel (two outer blocks: k_gemm<0>, fused k_step launches with pushes into future diagonal
+    blocks, K > 64 Schur updates) and a config-3-like 2-D stencil (swarm levels, k_update_small).  SHA-256 of inputs and of every
+    integer output, sampled entries of the factor at 1e-12, sum log|diag| and sum |entries|.  No oracle code runs here."""
+    import golden_large as GL
+    g = GL.load()[name]
+    c = GL.build_case(name)
+    GL.check_inputs_and_symbolic(name, g, c)
+    plan, Lsx = gpu_factor(c["sym"])
+    GL.check_factor(name, g, c["sym"], Lsx, TOL_FACTOR)
+    plan.close()
+
+
 def test_struct_entry_points_end_to_end(oracle, tmp_path):
     """the reference driver's call order (SparseFrame.c:3396-3423) through the struct ABI:
     BASELINE config 1 = 2-D 5-pt Laplacian 100x100 from a MatrixMarket file"""

@@ -305,6 +305,29 @@ def test_lu_golden_fixtures():
         plan.close()
 
 
+@pytest.mark.parametrize("fuse", ["", "0"], ids=["fused_step", "three_launches"])
+@pytest.mark.parametrize("name", ["piv_dense_200_tol01", "piv_zero_diag_12"])
+def test_lu_golden_fixtures_large(name, fuse, monkeypatch):
+    """tests/golden/large_sampled.json: a pivoted front of four 64-column blocks (accepted against the numpy statement of the block
+    rule) and a pivoted sparse factorization with a 666-column root (accepted by its solve against SuperLU's): full pivot sequence,
+    perturbation count, sampled factor entries, sum log|pivots|, sum |entries|.  No oracle code runs here."""
+    import golden_large as GL
+    if fuse:
+        monkeypatch.setenv("SF_FUSE_MAX", fuse)
+    g = GL.load()[name]
+    c = GL.build_case(name)
+    GL.check_inputs_and_symbolic(name, g, c)
+    S = c["sym"]
+    plan = sf.LUPlan(S)
+    plan.set_values(S.Lx, S.Ux)
+    plan.set_pivoting(g["tol"])
+    plan.factorize()
+    assert np.array_equal(plan.get_pivots(), np.asarray(g["pivpos"])), name
+    assert int(plan.stat("perturbed_pivots")) == g["perturbed"]
+    GL.check_factor(name, g, S, plan.get_factor(), 1e-11)
+    plan.close()
+
+
 @pytest.mark.parametrize("handlers", [1, 2])
 def test_struct_path_pivinv_and_factor_match_the_oracle(oracle, monkeypatch, handlers, struct_pivoting):
     """SparseFrame_factorize (LU library): matrix_info->PivInv and every value of matrix_info->Lsx against the oracle, with

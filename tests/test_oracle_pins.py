@@ -93,6 +93,26 @@ def test_numeric_against_dense_lapack(oracle, case, blas):
     oracle.blas_init("auto", threads=4)
 
 
+@pytest.mark.parametrize("name", ["chol_lap3d_24", "chol_stencil2d_200", "piv_dense_200_tol01", "piv_zero_diag_12"])
+def test_oracle_against_the_large_sampled_fixtures(oracle, name):
+    """the oracle (threaded BLAS back end; the fixtures were made with its built-in loops) against tests/golden/large_sampled.json,
+    whose values were accepted against dense LAPACK / SuperLU / the numpy block rule (tests/golden/make_golden_large.py)"""
+    import golden_large as GL
+    g = GL.load()[name]
+    c = GL.build_case(name)
+    GL.check_inputs_and_symbolic(name, g, c)
+    S = c["sym"]
+    oracle.blas_init("auto", threads=4)
+    if g["method"] == "cholesky":
+        Lsx, info, _ = oracle.chol_factorize(S)
+        assert info == 0
+        GL.check_factor(name, g, S, Lsx, 1e-12)
+    else:
+        Lsx, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=g["tol"])
+        assert info == 0 and nper == g["perturbed"] and np.array_equal(pivpos, np.asarray(g["pivpos"]))
+        GL.check_factor(name, g, S, Lsx, 1e-12)
+
+
 def test_not_positive_definite_is_reported(oracle):
     n, Cp, Ci, Cx = gen.laplacian_lower(6, 6)
     Cx = Cx.copy()

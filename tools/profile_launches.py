@@ -13,7 +13,7 @@ if wl == "stencil2d":
 elif wl == "lu":
     n, Cp, Ci, Cx = sf.gen.unsymmetric_stencil(g, g, g, extra_per_row=0, seed=2024, drop=0.05)
     sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g, 3, 1), sf.REFERENCE_SLOT_1GPU, "lu", False)
-    plan = sf.LUPlan(sym); plan.set_values(sym.Lx, sym.Ux)
+    plan = sf.LUPlan(sym); plan.set_values(sym.Lx, sym.Ux); plan.set_pivoting(0.1)
 else:
     n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
     sym = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g, 3, 1), sf.REFERENCE_SLOT_1GPU)
