@@ -247,9 +247,12 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan *plan, sf_comm *comm, sf_flo
  * sum per shared supernode in the forward sweep is all that travels. */
 int sf_chol_plan_solve_distributed(sf_chol_plan *plan, sf_comm *comm, const sf_float *b_host, sf_float *x_host);
 /* Failure behaviour of the two distributed drivers: everything that can fail on one rank alone is done first and the ranks agree on
- * the outcome with one 8-byte sum BEFORE the first data collective; if any rank failed, every rank returns (its own code, or
- * SF_ERR_PEER) with nothing enqueued on the communicator.  A failure in the middle of a run aborts this rank's communicator
- * (ncclCommAbort; emulated ranks keep their hand-shakes going): later calls on it return SF_ERR_PEER.
+ * the outcome with one 8-byte sum BEFORE the first data collective (a failed rank always joins that sum; its word is allocated with
+ * the plan); if any rank failed, every rank returns (its own code, or SF_ERR_PEER) with nothing enqueued on the communicator.  A
+ * failure in the MIDDLE of a run (a device or link failure by then) aborts THIS rank's communicator (ncclCommAbort, a local
+ * operation): this rank returns its error and later calls on the communicator return SF_ERR_PEER; RCCL peers already inside a
+ * collective are NOT released by that -- they rely on their own timeout / the job's supervisor.  Emulated ranks keep their host-side
+ * hand-shakes going, so all of them return.  The RCCL paths have been exercised with one rank only (no multi-GPU box so far).
  * sf_test_inject_failure (test hook): rank `rank` fails once at `where` = 1 before the first collective of a factorization, 2 in the
  * middle of its segments, 3 before the first collective of a solve, 4 in the middle of its forward sweep. */
 void sf_test_inject_failure(int rank, int where);
@@ -327,6 +330,9 @@ int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_inf
  * sf_lu_plan_set_pivoting).  sf_handlers_perturbed_pivots: perturbed pivots of the factorization that filled this host array
  * (-1: unknown array; with several handlers a shared panel's perturbations are counted once per rank that stores it). */
 int sf_handlers_set_lu_pivoting(double tol, double perturb);
+/* the policy of the NEXT sf_handlers_factorize call made by the calling thread only (how the LU struct library passes a
+ * matrix_info's own setting, SparseFrame_set_matrix_pivoting); precedence: this, the process-wide one, the plan's creation default */
+int sf_handlers_set_lu_pivoting_next_call(double tol, double perturb);
 int64_t sf_handlers_perturbed_pivots(const sf_float *Lsx_host);
 
 /* The struct path's solve with the RESIDENT factor: after SparseFrame_factorize the factor is still in the handler's cached plan (or
@@ -352,6 +358,7 @@ int sf_handlers_solve_resident_sym(const sf_float *Lsx_host, const sf_float *b, 
 void sf_handlers_forget(const sf_float *Lsx_host);
 int64_t sf_handlers_replica_mismatches(const sf_float* Lsx_host); /* values of shared panels that differ bitwise between ranks (tests; -1: not a multi-handler factor) */
 int64_t sf_handlers_resident_solves(void);     /* how many solves were served from a resident factor so far (tests) */
+int64_t sf_handlers_fingerprint_fallbacks(void); /* verified solves that found Lsx changed (fingerprint mismatch) and left the solve to the host sweep */
 
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
 int sf_device_count(void);

@@ -115,7 +115,7 @@ int SparseFrame_factorize_supernodal(struct common_info_struct *common_info, str
 
 /* Pivoting -- NOT in the reference, which never pivots (magma_dgetrf_nopiv L:2653, devIpiv = NULL L:3344; its static pre-pivot
  * L:589-673 is compiled out at L:784).  DEFAULT = the reference's behaviour: no interchanges, no perturbation, matrix_info->Lsx is
- * the reference's factor and matrix_info->PivInv the identity.  SparseFrame_set_pivoting(tol, perturb) (process-wide, before
+ * the reference's factor and matrix_info->PivInv the identity.  SparseFrame_set_pivoting(tol, perturb) (process-wide default, before
  * SparseFrame_factorize; or SF_LU_PIVOT_TOL in the environment) opts in to threshold partial pivoting inside the 64 x 64 diagonal
  * blocks of a supernode (tol in (0, 1], 1 = partial pivoting) and to the replacement of pivots below perturb * max|a_ij| by that
  * value.  CONTRACT when it is on: PivInv[g] = the row position original row g was given (same 64-column block; identity where
@@ -125,6 +125,11 @@ int SparseFrame_factorize_supernodal(struct common_info_struct *common_info, str
  * SparseFrame_perturbed_pivots: how many pivots the last factorization into this matrix_info's Lsx replaced (0 = the factor is
  * exact; > 0: refine the solution iteratively; -1 unknown). */
 int SparseFrame_set_pivoting(double tol, double perturb);
+/* the same for ONE matrix_info (overrides the process-wide setting for that matrix; dropped by SparseFrame_initialize_matrix /
+ * _cleanup_matrix).  The reference's driver factorizes MATRIX_THREAD_NUM matrices at a time over one handler list (L:3375): each
+ * may carry its own policy; a matrix without one gets the process-wide setting, else the reference's behaviour. */
+int SparseFrame_set_matrix_pivoting(struct matrix_info_struct *matrix_info, double tol, double perturb);
+int SparseFrame_clear_matrix_pivoting(struct matrix_info_struct *matrix_info);
 sf_long SparseFrame_perturbed_pivots(const struct matrix_info_struct *matrix_info);
 
 /* replaces L:3592-3700 (host triangular solves, reads Lsx/Bx, writes Xx) */

@@ -94,6 +94,10 @@ lib.sf_handlers_perturbed_pivots.argtypes = [C.c_void_p]
 lib.sf_handlers_perturbed_pivots.restype = C.c_int64
 lu_lib.SparseFrame_set_pivoting.argtypes = [C.c_double, C.c_double]
 lu_lib.SparseFrame_set_pivoting.restype = C.c_int
+lu_lib.SparseFrame_set_matrix_pivoting.argtypes = [C.c_void_p, C.c_double, C.c_double]
+lu_lib.SparseFrame_set_matrix_pivoting.restype = C.c_int
+lu_lib.SparseFrame_clear_matrix_pivoting.argtypes = [C.c_void_p]
+lu_lib.SparseFrame_clear_matrix_pivoting.restype = C.c_int
 lu_lib.SparseFrame_perturbed_pivots.argtypes = [C.c_void_p]
 lu_lib.SparseFrame_perturbed_pivots.restype = C.c_int64
 lib.sf_build_experiments.argtypes = []
@@ -104,6 +108,8 @@ lib.sf_handlers_set_resident_solve.argtypes = [C.c_int]
 lib.sf_handlers_set_resident_solve.restype = C.c_int
 lib.sf_handlers_resident_solves.argtypes = []
 lib.sf_handlers_resident_solves.restype = C.c_int64
+lib.sf_handlers_fingerprint_fallbacks.argtypes = []
+lib.sf_handlers_fingerprint_fallbacks.restype = C.c_int64
 lib.sf_handlers_plan_builds.argtypes = [C.c_void_p, C.c_int]
 lib.sf_handlers_plan_builds.restype = C.c_int64
 lib.sf_chol_plan_validate.argtypes = [C.c_void_p, c_double_p, c_double_p]

@@ -724,5 +724,9 @@ class LUMatrixInfo(MatrixInfo):
         """process-wide policy of the LU struct entry points (SparseFrame_set_pivoting): (0, 0) = the reference's behaviour"""
         check(lu_lib.SparseFrame_set_pivoting(float(tol), float(perturb)), "SparseFrame_set_pivoting")
 
+    def set_matrix_pivoting(self, tol=0.0, perturb=0.0):
+        """this matrix's own policy (SparseFrame_set_matrix_pivoting); overrides the process-wide one for this matrix_info"""
+        check(lu_lib.SparseFrame_set_matrix_pivoting(C.byref(self.c), float(tol), float(perturb)), "SparseFrame_set_matrix_pivoting")
+
     def perturbed_pivots(self):
         return int(lu_lib.SparseFrame_perturbed_pivots(C.byref(self.c)))

@@ -308,6 +308,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     int su_maxk = sf::SU_MAXK;              // SF_SU_MAXK: experiment knob
     if (const char* env = sf_exp_env("SF_SU_MAXK")) su_maxk = atoi(env);
     int32_t n_flags = 0;
+    // LU fused steps: the step for which panel s's diagonal block last received its pre-update (outer block * 16 + step), see below
+    std::vector<int32_t> pre_updated(lu ? (size_t)std::max<sf_long>(nsuper, 1) : 0, -1);
     int64_t max_diag_tasks = 0;     // k_step launches: scratch for the 16 x 16 inverses, 1024 doubles per diagonal task
     // steps of up to this many workgroups run as ONE k_step launch; beyond it (swarms of tiny panels at the bottom levels)
     // the three-launch form -- stream-K GEMM, one-wave POTRF, 256-row TRSM workgroups -- has the better throughput.
@@ -473,6 +475,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                         if (diag >= nscol) { flag_of.push_back(-1); slot_of.push_back(-1); continue; }
                         const int b = std::min(sf::NB, nscol - diag);
                         flag_of.push_back(n_flags);
+                        // (the two halves of an LU diagonal block's update are tied together here, not by convention: a diagonal task that
+                        // applies only the last 64 columns must find the pre-update task of the launch before it)
+                        if (lu && ti >= 2 && pre_updated[(size_t)s] != jo * 16 + ti) {
+                            fprintf(stderr, "[sparseframe-hip] plan_create: LU step %d of outer block %d of supernode %lld has no pre-update task\n", ti, jo, (long long)s);
+                            delete p;
+                            return SF_ERR_ARG;
+                        }
                         // Cholesky: J = diag (no left-looking update): the diagonal block arrives up to date, see k_step
                         // LU: the diagonal block's own left-looking update is cut in two -- its far part (columns [J, diag - 64): final
                         // before the PREVIOUS step starts) was applied by a pre-update task of that step's launch (below), the
@@ -491,6 +500,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                             if (dnext >= nscol) continue;
                             const int bn = std::min(sf::NB, nscol - dnext);
                             steps.push_back(StepTask{XP[s], XP[s] + ushift, nsrow, J, dnext, bn, dnext, bn, -1, 2, 0, 0, (int32_t)Super[s], 0});
+                            pre_updated[(size_t)s] = jo * 16 + ti + 1;
                         }
                     }
                     size_t si = 0;
@@ -1149,6 +1159,12 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             }
             if (!ok) { rc = SF_ERR_HIP; break; }
         }
+        if (nranks > 1) {
+            // the word of the ranks' status agreement (sf_multi.hip, agree_status) exists from the start: the agreement itself must not
+            // depend on an allocation that can fail on one rank alone
+            if (!dalloc((void**)&p->d_status, sizeof(double))) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += sizeof(double);
+        }
         if (p->partial) {
             std::vector<int8_t> mask(std::max<sf_long>(nsuper, 1), 0);
             // the matrix entries of a shared top panel enter the sum once: on the first rank of its group (load_top == 2),
@@ -1168,6 +1184,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 if (p->piv_tol > 0.0) p->piv_perturb = 1.4901161193847656e-08;      // sqrt(eps): pivoting comes with its fallback
             }
             if (const char* env = getenv("SF_LU_PERTURB")) p->piv_perturb = std::max(0.0, atof(env));
+            p->piv_tol0 = p->piv_tol; p->piv_perturb0 = p->piv_perturb;
             if (!p->u_alias) {
                 if ((rc = up(&p->d_Up, Up64))) break;
                 if ((rc = up(&p->d_Ui, Ui32))) break;
@@ -1719,6 +1736,7 @@ int sf_plan_import_from(sf_chol_plan* dst, sf_chol_plan* const* parts, int npart
     }
     dst->piv_tol = parts[0]->piv_tol;
     dst->piv_perturb = parts[0]->piv_perturb;
+    dst->hash_epoch = -1;           // the factor changed without a factorization of dst's own: cached fingerprints are stale
     HIP_TRY(hipStreamSynchronize(dst->stream));
     return SF_OK;
 }

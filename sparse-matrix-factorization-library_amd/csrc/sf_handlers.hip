@@ -103,15 +103,25 @@ struct Resident {
 std::mutex& g_res_mu = *new std::mutex();
 std::unordered_map<const void*, Resident>& g_resident = *new std::unordered_map<const void*, Resident>();
 int64_t g_resident_solves = 0;      // solves served from a resident factor (tests)
+std::atomic<int64_t> g_fingerprint_fallbacks{0};   // verified solves that fell back to the host sweep because a fingerprint differed (sf_handlers_fingerprint_fallbacks)
 // LU pivoting policy of the struct entry points (sf_handlers_set_lu_pivoting): unset = whatever the plans were created with (the
 // reference's behaviour, no pivoting, unless SF_LU_PIVOT_TOL said otherwise); g_perturbed: perturbed pivots of the factorization that filled a given host array
 std::mutex& g_piv_mu = *new std::mutex();
 bool g_piv_set = false;
 double g_piv_tol = 0.0, g_piv_perturb = 0.0;
 std::unordered_map<const void*, int64_t>& g_perturbed = *new std::unordered_map<const void*, int64_t>();
+// the policy of ONE call (sf_handlers_set_lu_pivoting_next_call: the struct library passes a matrix_info's own setting this way);
+// read by the thread that calls sf_handlers_factorize, before it hands the plans to the handlers' threads
+thread_local bool t_piv_set = false;
+thread_local double t_piv_tol = 0.0, t_piv_perturb = 0.0;
+// Every LU factorization through the handlers states its policy: the call's own, else the process-wide one, else what the plan was
+// created with -- a cached plan must not carry the previous matrix's setting into the next one's factorization.
 int apply_pivot_policy(sf_chol_plan* plan) {
+    if (!plan || !plan->lu) return SF_OK;
+    if (t_piv_set) return sf_lu_plan_set_pivoting(plan, t_piv_tol, t_piv_perturb);
     std::lock_guard<std::mutex> g(g_piv_mu);
-    return (g_piv_set && plan && plan->lu) ? sf_lu_plan_set_pivoting(plan, g_piv_tol, g_piv_perturb) : SF_OK;
+    return g_piv_set ? sf_lu_plan_set_pivoting(plan, g_piv_tol, g_piv_perturb)
+                     : sf_lu_plan_set_pivoting(plan, plan->piv_tol0, plan->piv_perturb0);
 }
 void note_perturbed(const void* Lsx, int64_t count) {
     std::lock_guard<std::mutex> g(g_piv_mu);
@@ -396,6 +406,7 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
                           const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                           const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
                           const sf_float* Lx, const sf_float* Ux, sf_float* Lsx_out, sf_long* PivOut) {
+    struct OneCallPolicy { ~OneCallPolicy() { t_piv_set = false; } } one_call_policy;      // sf_handlers_set_lu_pivoting_next_call holds for THIS call only
     if (!common || !Lsx_out || !Super || !Lsip || !Lsxp || !Lp || n < 0 || nsuper < 0) return SF_ERR_ARG;
     if (common->numGPU <= 0 || !list) {
         fprintf(stderr, "[sparseframe-hip] SparseFrame_factorize: no GPU handler (numGPU = %d); no CPU fallback\n", common->numGPU);
@@ -516,6 +527,7 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
                     for (int64_t sn = 0; sn < P0->nsuper; ++sn)
                         if (R.parts[r]->h_XP[sn] >= 0 && dh[sn] != hh[(size_t)sn]) {
                             g_resident.erase(it);
+                            ++g_fingerprint_fallbacks;
                             return why("the host copy differs from a rank's panel (fingerprint)");
                         }
                 }
@@ -557,7 +569,6 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
     // the host copy must still be what the device holds (it came from there bit by bit): the fingerprint of every panel of the
     // caller's array against the device's (one pass over the host array, threaded; the device side is cached per factorization)
     if (mode == 1) {
-        if (!R.parts.empty()) plan->hash_epoch = -1;        // a gathered plan: its content changes without a factorization of its own
         const uint64_t* dh = nullptr;
         if (sf_plan_panel_hashes(plan, &dh) != SF_OK) return why("the device fingerprints could not be computed");
         std::vector<uint64_t> hh;
@@ -565,6 +576,7 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
         for (int64_t sn = 0; sn < plan->nsuper; ++sn)
             if (dh[sn] != hh[(size_t)sn]) {
                 g_resident.erase(it);
+                ++g_fingerprint_fallbacks;
                 return why("the host copy differs from the device's (fingerprint)");
             }
     }
@@ -572,6 +584,11 @@ int sf_handlers_solve_resident_sym(const sf_float* Lsx_host, const sf_float* b, 
     if (!rc) ++g_resident_solves;
     return rc;
 }
+
+// how often a verified resident solve found the caller's array different from the device's factor and left the solve to the host sweep:
+// expected only after the caller changed Lsx; anything else (e.g. replicas of a shared panel that are no longer bit-identical) shows
+// up here instead of as a silently slower solve (bench.py reports it, the tests assert on it)
+int64_t sf_handlers_fingerprint_fallbacks(void) { return g_fingerprint_fallbacks.load(); }
 
 int sf_handlers_solve_resident(const sf_float* Lsx_host, const sf_float* b, sf_float* x) {
     return sf_handlers_solve_resident_sym(Lsx_host, b, x, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -649,6 +666,14 @@ int sf_handlers_set_lu_pivoting(double tol, double perturb) {
     g_piv_set = true;
     g_piv_tol = tol;
     g_piv_perturb = perturb;
+    return SF_OK;
+}
+
+int sf_handlers_set_lu_pivoting_next_call(double tol, double perturb) {
+    if (!(tol >= 0.0) || tol > 1.0 || !(perturb >= 0.0)) return SF_ERR_ARG;
+    t_piv_set = true;
+    t_piv_tol = tol;
+    t_piv_perturb = perturb;
     return SF_OK;
 }
 

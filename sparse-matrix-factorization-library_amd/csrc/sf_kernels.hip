@@ -1321,6 +1321,19 @@ void exp_set_step_stamps(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SY
 #define ST_STAMP(slot) do { } while (0)
 #endif
 
+// Agent-scope coherent load (global_load ... sc1): sees what another workgroup of the RUNNING launch -- possibly on another XCD, whose
+// L2 is not coherent with this one's -- stored and released before it raised a flag this workgroup has observed.  The row tasks
+// read the few values they take from their diagonal task this way (the factored 64 x 64 block, the 16 x 16 inverses, LU: the pivot
+// list) INSTEAD of an agent-scope acquire fence, which invalidates the whole XCD's L2 (buffer_inv sc1): 1.7 us per waiting
+// workgroup, 4 us with 500 of them polling (tools/experiments/README.md, step_fence.sh), and every co-resident task's cached
+// operands with it.
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool LU>
 __global__ void __launch_bounds__(256, LU ? SF_LU_STEP_WGS : 3)   // LU: the unblocked GETRF keeps a 64-value row per lane
 k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __restrict__ flags, int epoch, int* __restrict__ info,
@@ -1799,12 +1812,14 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
     if (tid == 0) {
         int spins = 0;
         // relaxed polls (an acquire load would invalidate this CU's caches at every iteration, and with hundreds of
-        // waiting workgroups that slows the whole chip down); ONE acquire fence once the flag is seen
+        // waiting workgroups that slows the whole chip down).  No acquire fence follows: everything this task reads of the
+        // diagonal task's output is read with agent-scope loads (ld_agent), issued after the barrier below, i.e. after the flag
+        // has been SEEN; the diagonal task released its stores (L2 write-back) before it raised the flag.
         while (__hip_atomic_load(flags + t.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             __builtin_amdgcn_s_sleep(16);
             if (++spins > ST_SPIN_LIMIT) { atomicOr(info, 2); break; }
         }
-#ifndef SF_EXP_NO_ACQUIRE_FENCE
+#ifdef SF_EXP_ACQUIRE_FENCE         // the former protocol (timing comparison only)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1822,7 +1837,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cj = 16 * q + fk + 4 * r;
-                src[4 * q + r] = (cj < b) ? pc.pivinv[g0 + cj] - g0 : cj;
+                src[4 * q + r] = (cj < b) ? ld_agent(pc.pivinv + g0 + cj) - g0 : cj;
                 ident = ident && src[4 * q + r] == cj;
             }
         if (!__all(ident)) {            // per wave; the waves' rows are disjoint, so is their part of the LDS image
@@ -1850,10 +1865,10 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 #pragma unroll
             for (int i = 0; i < NB * NB / 256; ++i) {       // all loads in flight (clamped addresses), then select + store
                 const int e = tid + 256 * i, k = e / NB, j = e % NB;
-                dv[i] = Dg[min(j, b - 1) + (int64_t)min(k, b - 1) * ld];
+                dv[i] = ld_agent(Dg + min(j, b - 1) + (int64_t)min(k, b - 1) * ld);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tv[i] = tsrc[tid + 256 * i];
+            for (int i = 0; i < 4; ++i) tv[i] = ld_agent(tsrc + tid + 256 * i);
 #pragma unroll
             for (int i = 0; i < NB * NB / 256; ++i) {
                 const int e = tid + 256 * i, k = e / NB, j = e % NB;
@@ -1931,7 +1946,12 @@ void launch_step(const StepTask* tasks, int ntasks, int lu, double* Lsx, int* fl
 // ~8 us per such pair with 7 of its 8 waves idle; here ONE WAVE owns a 64 x 32 tile (4 x 2 MFMA tiles), loads its
 // fragments straight from the source panel (no LDS, no barrier, up to 48 loads in flight) and scatters with the same
 // relative maps and fp64 atomics.  4 independent tiles per 256-thread workgroup.
-// (Measured variants: forcing 3 waves per SIMD / hoisting the relative-map loads made the compiler spill: 9.9 vs 7.7 ms.)
+// (Measured variants: forcing 3 waves per SIMD / hoisting the relative-map loads made the compiler spill: 9.9 vs 7.7 ms.
+// Round 4: PERSISTENT waves walking through chunks of 4 consecutive tiles with the next tile's descriptors prefetched, the map
+// entries requested before the K loop and 4-step fragment batches (100 VGPRs + 64 AGPRs, 3 waves per SIMD) -- 7.94 vs 7.68 ms at
+// 128^3, 1.65 vs 1.59 ms on config 3, 3.27 vs 3.06 ms on config 5 (gpurun_out r04_h / r04_i): the kernel is not bound by the
+// per-tile latency chain but by its load and atomic instructions through the texture path -- 24 eight-byte loads per k-group and
+// up to 32 atomics per lane and tile, nothing shared between waves.)
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_update_small(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks, int ntasks,

@@ -15,6 +15,8 @@
 #include <cstring>
 #include <string>
 #include <time.h>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -76,8 +78,15 @@ long sf_lu_abi_layout(const char* name) {
 int SparseFrame_allocate_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_allocate(common, list); }   // L:16-285
 int SparseFrame_free_gpu(struct common_info_struct* common, struct gpu_info_struct** list) { return sf_handlers_free(common, list); }       // L:287-366
 
+namespace {
+// per-matrix_info pivoting policy (SparseFrame_set_matrix_pivoting): side table keyed by the struct's address
+std::mutex g_mi_piv_mu;
+std::unordered_map<const void*, std::pair<double, double>> g_mi_piv;
+}
+
 int SparseFrame_initialize_matrix(struct matrix_info_struct* mi) {   // L:675-746
     if (!mi) return 1;
+    { std::lock_guard<std::mutex> g(g_mi_piv_mu); g_mi_piv.erase((const void*)mi); }
     const int serial = mi->serial;
     const char* path = mi->path;
     memset(mi, 0, sizeof(*mi));
@@ -241,13 +250,33 @@ int SparseFrame_factorize_supernodal(struct common_info_struct* common, struct g
     if (!mi->PivInv) mi->PivInv = (sf_long*)malloc((size_t)(mi->nrow > 0 ? mi->nrow : 1) * sizeof(sf_long));
     if (!mi->PivInv) return SF_ERR_ALLOC;
     for (sf_long j = 0; j < mi->nrow; ++j) mi->PivInv[j] = j;
+    {
+        std::lock_guard<std::mutex> g(g_mi_piv_mu);
+        auto it = g_mi_piv.find((const void*)mi);
+        if (it != g_mi_piv.end()) (void)sf_handlers_set_lu_pivoting_next_call(it->second.first, it->second.second);
+    }
     return sf_handlers_factorize(common, list, 1, mi->serial, mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi,
                                  mi->Lsxp, mi->Lp, mi->Li, mi->isSymmetric ? nullptr : mi->Up, mi->isSymmetric ? nullptr : mi->Ui,
                                  mi->Lx, mi->isSymmetric ? nullptr : mi->Ux, mi->Lsx, mi->PivInv);
 }
 
 // Pivoting is opt-in: by default the factor is the reference's (no interchanges, PivInv = identity, nothing perturbed).
+// SparseFrame_set_pivoting: the process-wide default of the struct path.  SparseFrame_set_matrix_pivoting: ONE matrix_info's own
+// setting (the reference's driver runs MATRIX_THREAD_NUM matrices at a time over one handler list, L:3375: two matrices may want
+// different policies).  matrix_info_struct is the reference's layout and has no field for it, so the setting lives in a side table
+// keyed by the struct's address; SparseFrame_initialize_matrix / _cleanup_matrix drop it.
 int SparseFrame_set_pivoting(double tol, double perturb) { return sf_handlers_set_lu_pivoting(tol, perturb); }
+int SparseFrame_set_matrix_pivoting(struct matrix_info_struct* mi, double tol, double perturb) {
+    if (!mi || !(tol >= 0.0) || tol > 1.0 || !(perturb >= 0.0)) return SF_ERR_ARG;
+    std::lock_guard<std::mutex> g(g_mi_piv_mu);
+    g_mi_piv[(const void*)mi] = {tol, perturb};
+    return SF_OK;
+}
+int SparseFrame_clear_matrix_pivoting(struct matrix_info_struct* mi) {
+    std::lock_guard<std::mutex> g(g_mi_piv_mu);
+    g_mi_piv.erase((const void*)mi);
+    return SF_OK;
+}
 sf_long SparseFrame_perturbed_pivots(const struct matrix_info_struct* mi) {
     return (mi && mi->Lsx) ? (sf_long)sf_handlers_perturbed_pivots(mi->Lsx) : -1;
 }

@@ -278,9 +278,16 @@ static bool injected(int rank, int where) {
     return true;
 }
 
-// A communicator that cannot go on (a failure between collectives of a running factorization or solve): RCCL peers may already sit
-// in kernels that wait for this rank, so the communicator and its sub-communicators are aborted (ncclCommAbort, when the library
-// has it) and marked dead -- every later call on them fails at once instead of enqueueing work nobody will match.
+// A communicator that cannot go on (a failure between collectives of a running factorization or solve).  What this does and does
+// NOT do: THIS rank's communicator and sub-communicators are aborted (ncclCommAbort, when the library has it) and marked dead, so
+// every later call on them fails at once instead of enqueueing work nobody will match.  It does NOT release the peers: a peer that
+// already sits in a collective this rank never joins keeps waiting there until ITS OWN side gives up (RCCL's watchdog / the
+// launcher's timeout -- bench.py sets 600 s -- or an abort by whoever supervises the job); ncclCommAbort is a local operation.
+// Everything that can fail on one rank alone is therefore done BEFORE the first data collective and agreed on (agree_status); a
+// failure after that point is a device or link failure, for which "this rank reports, the job is torn down from outside" is the
+// contract.  Emulated ranks (LocalGroup) are different: their hand-shakes are host-side and a failed rank keeps them going, so
+// the peers return too.  NOTE: the RCCL paths below have run on ONE rank only (no multi-GPU box in four rounds); the emulated
+// ranks exercise the same call sequence.
 static void abort_comm(sf_comm* c) {
     if (!c || c->kind != 0 || c->dead) return;
     c->dead = true;
@@ -290,11 +297,14 @@ static void abort_comm(sf_comm* c) {
 
 // Every rank of `comm` learns whether ANY of them has failed so far: one 8-byte sum on `st`, waited for on the host.  Called by all
 // ranks whatever their own state, BEFORE the first data collective of a run, so that no rank enqueues collectives a failed peer
-// will never match (those would spin on the GPU for ever).  Returns my_rc if this rank failed, SF_ERR_PEER if only others did.
+// will never match (those would spin on the GPU for ever).  A rank that has failed ALWAYS takes part and contributes 1: the status
+// word is allocated with the plan (no allocation here), so the only way not to join is a device that no longer accepts a memcpy --
+// then nothing this rank could enqueue would run either, and the peers are left to their timeouts (see abort_comm).
+// Returns my_rc if this rank failed, SF_ERR_PEER if only others did.
 static int agree_status(sf_chol_plan* p, sf_comm* comm, int my_rc, hipStream_t st) {
     if (comm->nranks == 1) return my_rc;
     bool ok = hipSetDevice(p->device) == hipSuccess;
-    if (ok && !p->d_status) ok = hipMalloc((void**)&p->d_status, sizeof(double)) == hipSuccess;
+    if (ok && !p->d_status) ok = hipMalloc((void**)&p->d_status, sizeof(double)) == hipSuccess;      // (plans made before round 4 only)
     double flag = my_rc ? 1.0 : 0.0, got = 1.0;
     ok = ok && hipMemcpyAsync(p->d_status, &flag, sizeof flag, hipMemcpyHostToDevice, st) == hipSuccess;
     int rc;
@@ -551,8 +561,8 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
     int rc_dl = SF_OK;
     if (host_out) rc_dl = sf_dl_end(p);         // (also releases the copy workers when rc != 0)
     if (rc) {
-        // in the middle of the segments: emulated peers were kept going by the hand-shakes above; RCCL peers may sit in a collective
-        // this rank never joined -- abort the communicator so that they (and every later call here) fail instead of hanging
+        // in the middle of the segments: emulated peers were kept going by the hand-shakes above; this rank's RCCL communicator is
+        // aborted and marked dead (later calls fail at once) -- peers already inside a collective wait for their own timeout, see abort_comm
         abort_comm(comm);
         (void)sf_chol_plan_sync(p);
         return rc;

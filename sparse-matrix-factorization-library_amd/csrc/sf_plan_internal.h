@@ -147,6 +147,7 @@ struct sf_chol_plan {
     // Defaults = the reference's behaviour: no pivoting, no perturbation (magma_dgetrf_nopiv, L:2653); opt-in by sf_lu_plan_set_pivoting,
     // SparseFrame_set_pivoting (struct path) or SF_LU_PIVOT_TOL / SF_LU_PERTURB at plan creation
     double piv_tol = 0.0, piv_perturb = 0.0, amax = 0;
+    double piv_tol0 = 0.0, piv_perturb0 = 0.0;      // the policy the plan was created with (environment or none): what a struct call without a policy of its own gets
     int32_t* d_piv = nullptr;   // pivpos[n] | pivinv[n] | perturbation counter
     int last_perturbed = 0;
     bool dry = false;           // schedule-only plan (plan_create's dry mode): no device resources, inspection only

@@ -876,33 +876,37 @@ void nd_component_big(NdCtx& c, std::vector<Long>& comp, Long pos, int team, Lon
 }
 
 
-// `verts`: vertices carrying one common mark, to be written to out[pos ..).  Its connected components are peeled off one after
-// the other (iteratively: a diagonal matrix has n components) and dissected.
+// `verts`: vertices carrying one common mark (sorted by vertex number when the piece is big), to be written to out[pos ..).  Its
+// connected components are found and dissected one after the other (iteratively: a diagonal matrix has n components).
+//   * a big piece is usually ONE component (a dissection half of a mesh): the team's BFS from its smallest vertex finds that out and
+//     the piece goes to nd_component_big as it is;
+//   * otherwise everything that is left is labelled in ONE sequential sweep -- a BFS per component from its smallest vertex, each
+//     vertex visited once -- and only the components that are big themselves go back to the team.  (Round 3 ran the team's BFS, a
+//     whole-piece filter and 2 (team - 1) thread starts PER COMPONENT: a piece of 10^5 vertices with many small components -- the
+//     identity rows of a finite-element matrix, a diagonal matrix -- went quadratic: n = 104,000 diagonal 34 s)
+// Which path a component takes depends on sizes and vertex numbers only, never on the number of threads.
 void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team) {
     const Long id = c.mk(verts[0]);
-    // big pieces (the input list is sorted by vertex number -- the whole graph is, and the big path only hands down filtered lists)
-    while ((Long)verts.size() >= ND_PAR_MIN) {
+    if ((Long)verts.size() >= ND_PAR_MIN) {
         std::vector<Long> order;
         Long last_min = 0;
         const Long cid = c.next_id++;
         (void)nd_bfs_team(c, id, verts[0], team, (Long)verts.size(), cid, order, &last_min);
-        std::vector<Long> comp, rest;
-        if (order.size() == verts.size()) comp.swap(verts);
-        else {
-            for (Long v : verts) (c.mk(v) == cid ? comp : rest).push_back(v);
-            verts.swap(rest);
-        }
+        const Long found = (Long)order.size();
         { std::vector<Long>().swap(order); }
-        const Long sz = (Long)comp.size();
-        if (sz >= ND_PAR_MIN) nd_component_big(c, comp, pos, team, last_min);
+        if (found == (Long)verts.size()) { nd_component_big(c, verts, pos, team, last_min); return; }
+        std::vector<Long> comp;
+        comp.reserve((size_t)found);
+        for (Long v : verts)
+            if (c.mk(v) == cid) comp.push_back(v);              // sorted in, sorted out
+        if (found >= ND_PAR_MIN) nd_component_big(c, comp, pos, team, last_min);
         else {
-            // a small component of a big piece: the sequential code wants it in BFS order from some vertex of it
+            // the sequential code wants the component in BFS order from some vertex of it (the team's order inside a level is a race)
             std::vector<Long> o2;
             nd_bfs(c, cid, comp[0], o2);
             nd_component(c, o2, pos);
         }
-        pos += sz;
-        if (verts.empty()) return;
+        pos += found;
     }
     std::vector<Long> comp;
     for (Long v : verts) {
@@ -911,7 +915,21 @@ void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team) {
         const Long cid = c.next_id++;
         for (Long w : comp) c.set_mk(w, cid);
         const Long sz = (Long)comp.size();
-        nd_component(c, comp, pos);
+        if (sz >= ND_PAR_MIN) {
+            // a big component behind smaller ones: level structure from the smallest vertex of the last level of this sweep (what the
+            // team's sweep would have reported), vertex list sorted by a filter of the piece's
+            const Long last = c.level[comp.back()];
+            Long root = comp.back();
+            for (size_t k = comp.size(); k-- > 0 && c.level[comp[k]] == last;) root = std::min(root, comp[k]);
+            std::vector<Long> sorted;
+            sorted.reserve((size_t)sz);
+            for (Long w : verts)
+                if (c.mk(w) == cid) sorted.push_back(w);
+            { std::vector<Long>().swap(comp); }
+            nd_component_big(c, sorted, pos, team, root);
+        } else {
+            nd_component(c, comp, pos);
+        }
         pos += sz;
     }
 }

@@ -334,8 +334,8 @@ def test_eight_emulated_handlers_at_the_largest_grid_one_gpu_holds(monkeypatch):
     Lsx = mi.array("Lsx", xsize)
     nan_chunks = sum(int(np.isnan(Lsx[o:o + (1 << 26)]).sum()) for o in range(0, xsize, 1 << 26))
     assert nan_chunks == 0
-    k = lib.sf_handlers_resident_solves()
+    k, fb = lib.sf_handlers_resident_solves(), lib.sf_handlers_fingerprint_fallbacks()
     assert mi.validate() <= 1e-13
-    assert lib.sf_handlers_resident_solves() == k + 1
+    assert lib.sf_handlers_resident_solves() == k + 1 and lib.sf_handlers_fingerprint_fallbacks() == fb
     mi.cleanup()
     common.close()

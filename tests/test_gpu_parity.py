@@ -729,8 +729,10 @@ def test_struct_solve_runs_on_the_resident_factor(oracle, monkeypatch):
     at = int(mi.array("Lsxp", int(mi.c.nsuper) + 1)[s_mid])
     keep = float(Lsx[at])
     Lsx[at] = np.nextafter(keep, 2 * keep)
+    fb = lib.sf_handlers_fingerprint_fallbacks()
     mi.validate()
     assert lib.sf_handlers_resident_solves() == before + 1            # host fallback
+    assert lib.sf_handlers_fingerprint_fallbacks() == fb + 1           # ... and it is counted, not silent
     Lsx[at] = keep
     mi.factorize(common)                                               # resident again
     # trusted mode: the caller vouches for Lsx, nothing is compared -- the device's factor answers even though the host copy differs

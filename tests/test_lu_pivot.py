@@ -204,6 +204,25 @@ def _zeroed_diagonal_case(N, seed, every):
     return n, Cp, Ci, Cx, perm
 
 
+def _blockdiag_dense_csc(sizes, seed, weak_every):
+    """independent dense unsymmetric blocks (one supernode each, all in ONE level set, widths that are no multiples of 64, one of them
+    wider than an outer block): the fused LU steps of that set carry panels that drop out at different steps, pre-update tasks for
+    some and not for others.  Every weak_every-th diagonal entry is made tiny, so rows really are interchanged."""
+    rng = np.random.default_rng(seed)
+    n = sum(sizes)
+    Cp, Ci, Cx = [0], [], []
+    o = 0
+    for k in sizes:
+        B = rng.uniform(-1, 1, (k, k)) + 0.5 * k ** 0.5 * np.eye(k)
+        B[np.arange(0, k, weak_every), np.arange(0, k, weak_every)] *= 1e-3
+        for j in range(k):
+            Ci.append(np.arange(o, o + k, dtype=np.int64))
+            Cx.append(B[:, j])
+            Cp.append(Cp[-1] + k)
+        o += k
+    return n, np.array(Cp, dtype=np.int64), np.concatenate(Ci), np.concatenate(Cx)
+
+
 def pivot_cases():
     c = []
     rng = np.random.default_rng(11)
@@ -216,6 +235,8 @@ def pivot_cases():
     c.append(("general_10_tol1", n, Cp, Ci, Cx, nd_perm_py(10, 10, 10), 1.0, 1e-10))
     n, Cp, Ci, Cx = gen.unsymmetric_general(14, 14, 14, seed=22, diag_scale=1.0)
     c.append(("general_14_tol03", n, Cp, Ci, Cx, nd_perm_py(14, 14, 14), 0.3, 1e-10))
+    # mixed panel widths in one level set, no multiples of 64, more than one outer block, pivoting on
+    c.append(("blockdiag_700_130_577_65_tol03", *_blockdiag_dense_csc((700, 130, 577, 65), 41, 5), None, 0.3, 1e-10))
     return c
 
 
@@ -411,4 +432,45 @@ def test_reanalysis_of_a_larger_matrix_resizes_pivinv(struct_pivoting):
         assert np.array_equal(mi.array("PivInv", n), np.arange(n))
         assert mi.validate() <= 1e-13
     mi.cleanup()
+    common.close()
+
+
+def test_two_matrices_with_their_own_pivot_settings_on_one_handler_list(oracle):
+    """per-matrix_info policy (SparseFrame_set_matrix_pivoting): matrix A pivots, matrix B -- the same pattern, so the same cached
+    device plan -- must not inherit that, and the other way round; the process-wide default stays the reference's behaviour"""
+    N = 10
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=4)
+    perm = nd_perm_py(N, N, N)
+    S0 = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    widths = np.diff(S0.Super)
+    Cz = Cx.copy()
+    cols = np.repeat(np.arange(n), np.diff(Cp))
+    for s in [s for s in range(S0.nsuper) if widths[s] >= 4][::4]:
+        g = S0.Perm[S0.Super[s]]
+        Cz[(Ci == g) & (cols == g)] = 0.0                   # exact zero pivots: only a pivoting factorization gets through
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    a, b = sf.LUMatrixInfo(), sf.LUMatrixInfo()
+    a.set_csc(n, Cp, Ci, Cz, symmetric=False)
+    a.set_perm(perm)
+    a.set_matrix_pivoting(0.1, 1.4901161193847656e-08)
+    b.set_csc(n, Cp, Ci, Cx, symmetric=False)
+    b.set_perm(perm)
+    a.analyze(common)
+    b.analyze(common)
+    builds = common.plan_builds()
+    for _ in range(2):
+        a.factorize(common)
+        assert np.count_nonzero(a.array("PivInv", n) != np.arange(n)) > 0 and a.validate() <= 1e-10
+        b.factorize(common)                                  # same plan, no policy of its own: the reference's no-pivot factor
+        assert np.array_equal(b.array("PivInv", n), np.arange(n)) and b.validate() <= 1e-13
+    assert common.plan_builds() == builds + 1               # one pattern, one plan
+    ref, info, _ = oracle.lu_factorize(sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False))
+    assert rel_err(b.array("Lsx", int(b.c.xsize)), ref) <= 1e-12
+    # without its policy matrix A meets its zero pivot, as the reference would
+    lu_lib = sf._lib.lu_lib
+    assert lu_lib.SparseFrame_clear_matrix_pivoting(__import__("ctypes").byref(a.c)) == 0
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_NOT_POSDEF"):
+        a.factorize(common)
+    a.cleanup()
+    b.cleanup()
     common.close()

@@ -87,3 +87,47 @@ def test_builtin_ordering_fill_quality_figure():
         blt = sf.analyze(n, Cp, Ci, Cx, sf.graph_nd_perm(n, Cp, Ci), 8 << 30)
         assert blt.flops_struct <= bound * geo.flops_struct, (dims, blt.flops_struct / geo.flops_struct)
         assert blt.ColCount.sum() <= geo.ColCount.sum()
+
+
+def _isolated_boundary_grid(g):
+    """g^3 7-point grid whose boundary rows are identity rows (Dirichlet rows of a finite-element matrix): one big component and
+    6 g^2 - 12 g + 8 isolated vertices, the smallest vertex numbers among them"""
+    n, Cp, Ci, Cx = gen.laplacian_lower(g, g, g)
+    idx = np.arange(n)
+    x, y, z = idx % g, (idx // g) % g, idx // (g * g)
+    bnd = (x == 0) | (x == g - 1) | (y == 0) | (y == g - 1) | (z == 0) | (z == g - 1)
+    cols = np.repeat(idx, np.diff(Cp))
+    keep = (Ci == cols) | (~bnd[Ci] & ~bnd[cols])
+    Cp2 = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols[keep], minlength=n), out=Cp2[1:])
+    return n, Cp2, Ci[keep], Cx[keep]
+
+
+def test_many_components_in_a_big_piece_stay_linear():
+    """pieces of >= 100,000 vertices peeled their components off one team-BFS at a time -- a diagonal matrix of 104,000
+    rows took 34 s (0.009 s at 99,999), 10^6 did not finish.  Now one sweep labels everything that is left."""
+    import time
+    for n in (104000, 1000000):
+        t0 = time.perf_counter()
+        p = sf.graph_nd_perm(n, np.arange(n + 1), np.arange(n))
+        dt = time.perf_counter() - t0
+        assert len(np.unique(p)) == n and p.min() == 0 and p.max() == n - 1
+        assert dt < 5.0, (n, dt)        # 0.01 s / 0.14 s measured; the quadratic form needed minutes
+    n, Cp, Ci, Cx = _isolated_boundary_grid(52)        # 140,608 vertices, 15,608 of them isolated, vertex 0 among them
+    t0 = time.perf_counter()
+    p = sf.graph_nd_perm(n, Cp, Ci)
+    dt = time.perf_counter() - t0
+    assert len(np.unique(p)) == n and dt < 5.0, dt
+    # the big component (125,000 interior vertices) still gets a real dissection: far less fill than the natural order
+    ident = sf.analyze(n, Cp, Ci, Cx, None, 8 << 30)
+    nd = sf.analyze(n, Cp, Ci, Cx, p, 8 << 30)
+    assert nd.flops_struct < 0.2 * ident.flops_struct
+
+
+def test_big_component_behind_small_ones_is_independent_of_the_thread_count(monkeypatch):
+    n, Cp, Ci, _ = _isolated_boundary_grid(52)
+    perms = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("SF_ANALYZE_THREADS", threads)
+        perms.append(sf.graph_nd_perm(n, Cp, Ci))
+    assert np.array_equal(perms[0], perms[1]) and np.array_equal(perms[0], perms[2])
