@@ -127,9 +127,17 @@ def mfma_roofline_schur(plan, ms, lu=False):
     upd_ms = plan.stat("last_update_ms")
     big = plan.stat("flops_update") - plan.stat("flops_update_small")
     ach = big / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+    traffic, src = None, None
+    if lu:          # HBM bytes per launch of that kernel from the committed PMC passes of config 5 (not measurable live)
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_lu_config5.json")))
+        if files:
+            with open(files[-1]) as f:
+                traffic = json.load(f).get("k_gemm<1>", {}).get("hbm_bytes_per_launch")
+            src = "committed rocprofv3 --pmc passes (profiles/), NOT measured in this run: " + os.path.basename(files[-1])
     return {"bound": "mfma", "kernel": "k_gemm<1> (Schur update, fused scatter%s)" % (", L and U^T sides" if lu else ""),
             "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "kernel_ms": round(upd_ms, 3), "algorithmic_flops": big,
+            "traffic": traffic, "traffic_source": src, "kernel_ms": round(upd_ms, 3), "algorithmic_flops": big,
             "whole_factorization_exec_TFLOPs": round(plan.stat("flops_exec") / (ms * 1e-3) / 1e12, 2),
             "whole_factorization_frac": round(plan.stat("flops_exec") / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
 
@@ -464,9 +472,10 @@ def main():
         # HBM traffic of that kernel: not measurable live (PMC counters need rocprofv3); taken from the committed
         # PMC passes of this exact workload when they exist (profiles/*_pmc_traffic_128cubed.json, bytes per launch)
         traffic = None
-        if N == 128 and not lu and args.workload == "lap3d":
+        files = []
+        if (N == 128 and not lu and args.workload == "lap3d") or (N == 79 and lu):
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_128cubed.json")))
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_lu_config5.json" if lu else "*_pmc_traffic_128cubed.json")))
             if files:
                 with open(files[-1]) as f:
                     traffic = json.load(f).get("k_gemm<1>", {}).get("hbm_bytes_per_launch")

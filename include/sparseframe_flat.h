@@ -204,6 +204,12 @@ sf_long sf_chol_plan_num_launches(const sf_chol_plan *plan);
 int sf_chol_plan_launch_info(const sf_chol_plan *plan, sf_long k, sf_long *out10);
 int sf_chol_plan_segment_info(const sf_chol_plan *plan, sf_long k, sf_long *out6);
 int sf_chol_plan_panel_offsets(const sf_chol_plan *plan, sf_long *xp);
+/* OWNER-COMPUTES PROTOTYPE (environment SF_TOP_OWNER=1 at plan creation, Cholesky): in the sets every rank takes
+ * part in (the root separator) the near GEMM and the 64-column chain of a 512-column block run on ONE rank (block number mod group
+ * size) and the finished block column is broadcast before the split far GEMMs that read it -- instead of running replicated on
+ * every rank.  out2[0] = owner's index in the group (-1: replicated, the default), out2[1] = launches of the owner's part.
+ * Measured and NOT the default: DESIGN.md section 7. */
+int sf_chol_plan_segment_owner(const sf_chol_plan *plan, sf_long k, sf_long *out2);
 sf_long sf_chol_plan_num_solve_reduces(const sf_chol_plan *plan);
 int sf_chol_plan_solve_reduce_info(const sf_chol_plan *plan, sf_long k, sf_long *out3);
 /* bit r set = rank r takes part in the all-reduce of segment k */

@@ -154,6 +154,8 @@ lib.sf_chol_plan_launch_info.argtypes = [C.c_void_p, C.c_int64, c_long_p]
 lib.sf_chol_plan_launch_info.restype = C.c_int
 lib.sf_chol_plan_segment_info.argtypes = [C.c_void_p, C.c_int64, c_long_p]
 lib.sf_chol_plan_segment_info.restype = C.c_int
+lib.sf_chol_plan_segment_owner.argtypes = [C.c_void_p, C.c_int64, c_long_p]
+lib.sf_chol_plan_segment_owner.restype = C.c_int
 lib.sf_chol_plan_panel_offsets.argtypes = [C.c_void_p, c_long_p]
 lib.sf_chol_plan_panel_offsets.restype = C.c_int
 lib.sf_chol_plan_num_solve_reduces.argtypes = [C.c_void_p]

@@ -303,6 +303,10 @@ class _ScheduleMixin:
         """int64[segments, 6]: SEGMENT_FIELDS per segment = per all-reduce of the factorization, in issue order"""
         return self._table(int(lib.sf_chol_plan_num_segments(self._h)), lib.sf_chol_plan_segment_info, 6)
 
+    def segment_owner_table(self):
+        """int64[segments, 2]: (owner's group index or -1, launches of the owner's part) -- the owner-computes prototype, SF_TOP_OWNER=1"""
+        return self._table(int(lib.sf_chol_plan_num_segments(self._h)), lib.sf_chol_plan_segment_owner, 2)
+
     def solve_reduce_table(self):
         """int64[reduces, 3]: (group mask, first column, columns) of the forward sweep's sums, in issue order"""
         return self._table(int(lib.sf_chol_plan_num_solve_reduces(self._h)), lib.sf_chol_plan_solve_reduce_info, 3)

@@ -324,6 +324,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // rank's own rounding.  Everything a chain reads is either an all-reduced sum or computed in a fixed order -- the step kernels,
     // and the look-ahead schedule's replicated near parts, which run k_gemm with whole_tiles: one addition per target element.)
     if (const char* env = getenv("SF_LOOKAHEAD")) p->lookahead = atoi(env) != 0;      // 0: the round-1 schedule (tests cover both)
+    if (const char* env = getenv("SF_TOP_OWNER")) p->top_owner = atoi(env) != 0 && !lu;   // prototype schedule (Cholesky), see Segment::owner_gi
     if (const char* env = sf_exp_env("SF_LOOKAHEAD1")) p->lookahead1 = atoi(env) != 0 && nranks == 1 && !p->partial;
     if (const char* env = sf_exp_env("SF_LOOKAHEAD1_GRID")) p->la_grid = std::max(0, atoi(env));
     int n_la_events = 0;
@@ -445,6 +446,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     }
                 }
                 sg.early = ahead && jo > 0;
+                // owner-computes prototype: the sets EVERY rank takes part in (the root separator), look-ahead schedule only
+                if (p->top_owner && ahead && LS.share_cnt == nranks) sg.owner_gi = jo % LS.share_cnt;
                 p->segments.push_back(std::move(sg));
                 if (ahead && jo > 0) outer_gemm(J, (jo - 1) * KT_BLOCK, jo * KT_BLOCK, false, true);       // block jo-1 -> block jo, replicated
             }
@@ -571,8 +574,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 if ((int64_t)potrf.size() > p0) p->launches.push_back(Launch{0, p0, (int)(potrf.size() - p0)});
                 if ((int64_t)trsm.size() > t0) p->launches.push_back(Launch{1, t0, (int)(trsm.size() - t0)});
             }
-            for (sf_long s : Sl)
-                if (J < Super[s + 1] - Super[s]) blk_ready[blk_first[s] + jo] = p->launches.size();
+            const bool owner_block = shared && !p->segments.empty() && p->segments.back().owner_gi >= 0;
+            if (owner_block) p->segments.back().lc = p->launches.size();       // near GEMM + chain = the owner's part; then the broadcast
+            for (sf_long s : Sl)        // (owner-computes: final on every rank only after the broadcast, i.e. once the next launch is in)
+                if (J < Super[s + 1] - Super[s]) blk_ready[blk_first[s] + jo] = p->launches.size() + (owner_block ? 1 : 0);
             if (ahead && jo + 2 < nouter) outer_gemm(J + 2 * sf::OUTER_NB, 0, (jo + 1) * KT_BLOCK, true, true);    // blocks 0 .. jo -> block jo+2
             if (ahead1 && jo + 2 < nouter && !p->launches.empty()) {
                 chain_ev[jo] = n_la_events++;
@@ -1149,8 +1154,11 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             int64_t mx = 1;
             for (const Segment& sg : p->segments) mx = std::max(mx, sg.packed);
             p->scratch_elems = mx;
-            if (!dalloc((void**)&p->d_scratch, 2 * mx * sizeof(double))) { rc = SF_ERR_ALLOC; break; }
-            p->bytes_device += 2 * mx * sizeof(double);
+            bool any_owner = false;
+            for (const Segment& sg : p->segments) any_owner = any_owner || sg.owner_gi >= 0;
+            const size_t nbuf = any_owner ? 3 : 2;          // owner-computes: the broadcast has a buffer of its own (the next block's sum may be in flight)
+            if (!dalloc((void**)&p->d_scratch, nbuf * mx * sizeof(double))) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += nbuf * mx * sizeof(double);
             bool ok = dry || p->stream2 || new_stream(&p->stream2, hipStreamNonBlocking);
             for (int k = 0; k < 2 && !dry; ++k) {
                 ok = ok && hipEventCreateWithFlags(&p->ev_contrib[k], hipEventDisableTiming) == hipSuccess;
@@ -1620,6 +1628,16 @@ int sf_chol_plan_segment_info(const sf_chol_plan* p, sf_long k, sf_long* out) {
     return SF_OK;
 }
 
+// owner-computes prototype (SF_TOP_OWNER=1): out[0] = group index of the rank that runs the block's near GEMM and chain (-1: everybody,
+// the default), out[1] = number of launches of that part (the segment's first out[1] launches)
+int sf_chol_plan_segment_owner(const sf_chol_plan* p, sf_long k, sf_long* out) {
+    if (!p || !out || k < 0 || k >= (sf_long)p->segments.size()) return SF_ERR_ARG;
+    const Segment& sg = p->segments[(size_t)k];
+    out[0] = sg.owner_gi;
+    out[1] = sg.owner_gi >= 0 ? (sf_long)(sg.lc - sg.l0) : 0;
+    return SF_OK;
+}
+
 int sf_chol_plan_panel_offsets(const sf_chol_plan* p, sf_long* xp) {
     if (!p || (!xp && p->nsuper > 0)) return SF_ERR_ARG;
     for (int64_t s = 0; s < p->nsuper; ++s) xp[s] = p->h_XP[(size_t)s];
@@ -1688,7 +1706,14 @@ int sf_chol_plan_factorize_segment(sf_chol_plan* p, sf_long k, int sync) {
         if (rc) return rc;
         p->packed_pending = -1;
     }
-    return run_launches(p, sg.l0, sg.l1, false, k + 1 == (sf_long)p->segments.size(), sync);
+    const bool last = k + 1 == (sf_long)p->segments.size();
+    if (sg.owner_gi >= 0) {
+        // owner-computes prototype driven from outside (tools/emulate_rank.py: no collectives, timing only): the owner's part, then the rest
+        const bool mine = sg.owner_gi == __builtin_popcount(sg.mask & ((1u << p->rank) - 1u));
+        if (mine && sg.lc > sg.l0) { const int rc = run_launches(p, sg.l0, sg.lc, false, false, 0); if (rc) return rc; }
+        return run_launches(p, sg.lc, sg.l1, false, last, sync);
+    }
+    return run_launches(p, sg.l0, sg.l1, false, last, sync);
 }
 
 }  // extern "C"
@@ -1779,7 +1804,42 @@ int sf_seg_finish(sf_chol_plan* p, sf_long k) {
     if (rc) return rc;
     HIP_TRY(hipEventRecord(p->ev_unpacked[h], p->stream));
     p->unpacked_recorded[h] = true;
+    if (sg.owner_gi >= 0) {
+        // the owner's part only (near GEMM + chain); sf_seg_bcast_begin / _finish follow
+        const bool mine = sg.owner_gi == __builtin_popcount(sg.mask & ((1u << p->rank) - 1u));
+        return (mine && sg.lc > sg.l0) ? run_launches(p, sg.l0, sg.lc, false, false, 0) : SF_OK;
+    }
     return run_launches(p, sg.l0, sg.l1, false, k + 1 == (sf_long)p->segments.size(), 0);
+}
+int sf_seg_is_owner_segment(const sf_chol_plan* p, sf_long k) {
+    return (p && k >= 0 && k < (sf_long)p->segments.size() && p->segments[(size_t)k].owner_gi >= 0) ? 1 : 0;
+}
+int sf_seg_bcast_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count) {
+    if (!p || k < 0 || k >= (sf_long)p->segments.size() || !dptr || !count) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    const Segment& sg = p->segments[(size_t)k];
+    if (sg.owner_gi < 0) return SF_ERR_ARG;
+    double* buf = p->d_scratch + 2 * p->scratch_elems;
+    const bool mine = sg.owner_gi == __builtin_popcount(sg.mask & ((1u << p->rank) - 1u));
+    if (mine) { const int rc = seg_copy(p, sg, buf, true, p->stream); if (rc) return rc; }
+    else if (sg.packed > 0) HIP_TRY(hipMemsetAsync(buf, 0, (size_t)sg.packed * sizeof(double), p->stream));
+    *dptr = (void*)buf;
+    *count = sg.packed;
+    return SF_OK;
+}
+int sf_seg_bcast_finish(sf_chol_plan* p, sf_long k) {
+    if (!p || k < 0 || k >= (sf_long)p->segments.size()) return SF_ERR_ARG;
+    if (p->dry) return SF_ERR_ARG;
+    HIP_TRY(hipSetDevice(p->device));
+    const Segment& sg = p->segments[(size_t)k];
+    if (sg.owner_gi < 0) return SF_ERR_ARG;
+    const int rc = seg_copy(p, sg, p->d_scratch + 2 * p->scratch_elems, false, p->stream);
+    if (rc) return rc;
+    // the block column is final on this rank NOW: its copy-back pieces carry "ready = lc + 1"; with launches behind the broadcast
+    // run_launches publishes them after the first of those, without any it is done here
+    if (p->dl_active && sg.lc == sg.l1) HIP_TRY(dl_publish(p, sg.lc + 1));
+    return run_launches(p, sg.lc, sg.l1, false, k + 1 == (sf_long)p->segments.size(), 0);
 }
 int sf_seg_early(const sf_chol_plan* p, sf_long k) { return (p && k >= 0 && k < (sf_long)p->segments.size() && p->segments[k].early) ? 1 : 0; }
 
@@ -2092,7 +2152,8 @@ int sf_dl_end(sf_chol_plan* p) {
     if (!p || !p->dl_active) return SF_ERR_ARG;
     // a factorization that stopped early (an error in the enqueue path) must still release the workers
     if (p->dl_next_ev < p->dl_ev_ready.size()) {
-        if (hipSetDevice(p->device) != hipSuccess || dl_publish(p, p->launches.size()) != hipSuccess) dl_fail(p, SF_ERR_HIP);
+        // (everything: an owner-computes block at the very end of the plan is ready "one launch after" its chain, see plan_create)
+        if (hipSetDevice(p->device) != hipSuccess || dl_publish(p, (size_t)-1) != hipSuccess) dl_fail(p, SF_ERR_HIP);
         if (p->dl_next_ev < p->dl_ev_ready.size()) dl_fail(p, SF_ERR_HIP);
     }
     for (std::thread& t : p->dl_threads) t.join();

@@ -547,16 +547,30 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
     for (sf_long k = 0; k < nseg; ++k) {
         if (!rc && k == nseg / 2 && injected(p->rank, 2)) rc = SF_ERR_HIP;
         if (rc) {
+            sf_comm* gc = group_comm(comm, p->segments[k].mask);
             if (!begun[k]) {
-                sf_comm* gc = group_comm(comm, p->segments[k].mask);
                 if (gc && gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, sf_plan_stream2(p));
                 begun[k] = 1;
             }
+            if (sf_seg_is_owner_segment(p, k) && gc && gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, (void*)p->stream);   // its broadcast
             continue;
         }
         if (!begun[k]) rc = begin(k);
         if (!rc && k + 1 < nseg && !begun[k + 1] && sf_seg_early(p, k + 1)) rc = begin(k + 1);
         if (!rc) rc = sf_seg_finish(p, k);
+        if (sf_seg_is_owner_segment(p, k)) {
+            // owner-computes prototype (SF_TOP_OWNER=1): only the block's owner has run its chain; its finished block column now
+            // travels to the group as a sum whose other terms are zero, on the MAIN stream (the far GEMMs behind it read the block)
+            sf_comm* gc = group_comm(comm, p->segments[k].mask);
+            void* buf = nullptr;
+            sf_long cnt = 0;
+            if (!rc) rc = gc ? sf_seg_bcast_begin(p, k, &buf, &cnt) : SF_ERR_ARG;
+            if (rc) { if (gc && gc->kind == 1) (void)sf_comm_allreduce_sum(gc, nullptr, -1, (void*)p->stream); continue; }
+            rc = sf_comm_allreduce_sum(gc, buf, cnt, (void*)p->stream);
+            if (rc && getenv("SF_TRACE")) fprintf(stderr, "[sparseframe-hip] rank %d: broadcast of segment %lld failed (%d)\n", p->rank, (long long)k, rc);
+            if (!rc) rc = sf_seg_bcast_finish(p, k);
+            if (rc && getenv("SF_TRACE")) fprintf(stderr, "[sparseframe-hip] rank %d: segment %lld after its broadcast failed (%d)\n", p->rank, (long long)k, rc);
+        }
     }
     int rc_dl = SF_OK;
     if (host_out) rc_dl = sf_dl_end(p);         // (also releases the copy workers when rc != 0)
@@ -569,6 +583,7 @@ int sf_chol_plan_factorize_distributed(sf_chol_plan* p, sf_comm* comm, sf_float*
     }
     if (sync || host_out) {
         const int rs = sf_chol_plan_sync(p);
+        if ((rs || rc_dl) && getenv("SF_TRACE")) fprintf(stderr, "[sparseframe-hip] rank %d: sync %d, copy-back %d\n", p->rank, rs, rc_dl);
         return rs ? rs : rc_dl;
     }
     return SF_OK;

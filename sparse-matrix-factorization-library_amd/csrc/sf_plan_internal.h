@@ -56,6 +56,12 @@ struct Segment {
     // them (which the segment's own first launch adds, replicated) is enqueued before the PREVIOUS segment starts, so the sum
     // over the ranks may run beside the previous segment's chain
     bool early = false;
+    // OWNER-COMPUTES prototype (SF_TOP_OWNER=1): the near GEMM and the 64-column chain of this block column,
+    // launches [l0, lc), run on ONE rank of the group only (group index owner_gi = block number mod group size); the finished block
+    // column is then broadcast to the group before the launches [lc, l1) (the split far GEMMs, which read it).  -1: everybody runs
+    // everything (the default: replicate and all-reduce).
+    int owner_gi = -1;
+    size_t lc = 0;
 };
 
 #define HIP_TRY(expr)                                                                       \
@@ -175,6 +181,7 @@ struct sf_chol_plan {
     bool lookahead1 = false;       // ONE GPU: the far part of block jo+2's update on the second stream beside the chain of block jo+1 (experiment)
     int la_grid = 0;               // workgroups of a lane-1 GEMM (0 = the full persistent grid)
     std::vector<hipEvent_t> la_events;
+    bool top_owner = false;        // SF_TOP_OWNER=1: owner-computes chains for the sets every rank takes part in (prototype, see Segment)
     bool lookahead = true;         // shared top panels: outer GEMM split into a far part (ahead of the previous chain) and the last block's
     hipStream_t stream2 = nullptr; // the collectives of look-ahead segments and their pack copies
     hipEvent_t ev_contrib[2] = {nullptr, nullptr}, ev_reduced[2] = {nullptr, nullptr}, ev_unpacked[2] = {nullptr, nullptr};
@@ -273,4 +280,10 @@ int sf_seg_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count);
 void* sf_plan_stream2(sf_chol_plan* p);
 int sf_seg_reduced(sf_chol_plan* p, sf_long k);
 int sf_seg_finish(sf_chol_plan* p, sf_long k);
+// owner-computes segments (Segment::owner_gi >= 0): sf_seg_finish runs only the owner's part [l0, lc); then the broadcast --
+// sf_seg_bcast_begin packs the finished block column on the owner / zeroes the buffer elsewhere (main stream), the caller sums the
+// buffer over the group (x + 0 + ... + 0: every rank gets the owner's values), sf_seg_bcast_finish scatters it back and runs [lc, l1)
+int sf_seg_is_owner_segment(const sf_chol_plan* p, sf_long k);
+int sf_seg_bcast_begin(sf_chol_plan* p, sf_long k, void** dptr, sf_long* count);
+int sf_seg_bcast_finish(sf_chol_plan* p, sf_long k);
 int sf_seg_early(const sf_chol_plan* p, sf_long k);

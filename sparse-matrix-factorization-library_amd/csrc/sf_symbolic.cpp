@@ -309,10 +309,17 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     tm_[1] = now_();
 
     std::vector<Long> Parent, Post, Count;
+    double te_[5]; te_[0] = now_();
     elimination_tree(S, Parent);
+    te_[1] = now_();
     postorder(Parent, nullptr, Post);
+    te_[2] = now_();
     column_counts(S, Parent, Post, Count);
+    te_[3] = now_();
     postorder(Parent, &Count, Post);
+    te_[4] = now_();
+    if (tr_) fprintf(stderr, "[sparseframe-hip]   etree %.1f ms, postorder %.1f ms, column counts %.1f ms, weighted postorder %.1f ms\n",
+                     te_[1] - te_[0], te_[2] - te_[1], te_[3] - te_[2], te_[4] - te_[3]);
 
     tm_[2] = now_();
     S.Post = Post;

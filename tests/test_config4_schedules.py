@@ -257,6 +257,25 @@ def test_the_checker_notices_a_rank_that_disagrees(monkeypatch):
     fails(plans_with(3, lambda: sf.Schedule(sym, owner, 2, 4)))            # rank 3 running rank 2's plan: windows overlap, panels missing
 
 
+def test_owner_computes_prototype_all_ranks_agree(monkeypatch):
+    """SF_TOP_OWNER=1: every member of the root's group names the same owner and the same owner's part for every block; the
+    owners rotate over the group; the cross-rank invariants (i) .. (v) hold for this schedule too"""
+    monkeypatch.setenv("SF_TOP_OWNER", "1")
+    sym, owner, _ = _laplacian_case(64, 8)
+    plans = [sf.Schedule(sym, owner, r, 8) for r in range(8)]
+    try:
+        tabs = [np.c_[p.segment_table()[:, G["mask"]], p.segment_owner_table()] for p in plans]
+        root = [t[t[:, 0] == 255][:, 1:] for t in tabs]
+        assert len(root[0]) >= 8 and all(np.array_equal(root[0], r) for r in root[1:])
+        assert np.array_equal(root[0][:, 0], np.arange(len(root[0])) % 8) and np.all(root[0][:, 1] > 0)
+        for t in tabs:
+            assert np.all(t[t[:, 0] != 255][:, 1] == -1)            # smaller groups keep the replicated schedule
+        check_schedules(sym, owner, 8, plans=plans)
+    finally:
+        for p in plans:
+            p.close()
+
+
 def test_a_schedule_only_plan_cannot_compute():
     sym, owner, _ = _laplacian_case(12, 2)
     sc = sf.Schedule(sym, owner, 0, 2)

@@ -65,6 +65,19 @@ def test_lookahead_schedule_three_outer_blocks(oracle, monkeypatch, nh, lookahea
     _chol_case(oracle, 34, nh)
 
 
+@pytest.mark.parametrize("nh,N", [(2, 34), (3, 34), (4, 40), (8, 40)])
+def test_owner_computes_prototype_matches_the_oracle(oracle, monkeypatch, nh, N):
+    """SF_TOP_OWNER=1 (SURVEY 8f rank 4 prototype): in the root separator's set the near GEMM and the 64-column
+    chain of a 512-column block run on ONE rank (block number mod group size), the finished block column is broadcast (a sum whose
+    other terms are zero) before the split far GEMMs that read it.  Same factor as the replicated schedule to rounding, replicas
+    bit-identical, every entry of Lsx written, cached plans on the second call.  34^3: 3 outer blocks in the root, 40^3: 4."""
+    if sf.device_count() != 1:
+        pytest.skip("emulated handlers are for one-GPU boxes")
+    monkeypatch.setenv("SF_EMULATE_HANDLERS", str(nh))
+    monkeypatch.setenv("SF_TOP_OWNER", "1")
+    _chol_case(oracle, N, nh)
+
+
 @pytest.mark.parametrize("nh,N", [(2, 64), (4, 64), (8, 96)])
 def test_emulated_handlers_large_by_residual(monkeypatch, nh, N):
     """64^3 over 2 / 4 emulated handlers: the root separator has 8 outer blocks, its children 4 (groups of 2 at nh = 4), and the

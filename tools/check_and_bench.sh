@@ -1,3 +1,4 @@
+# GPU suite + the three bench lines (LU config 5, config 3, 128^3) in one gpurun call: bash tools/check_and_bench.sh TAG
 set -e
 cd $GRAFT_REPO_ROOT
 T=$1
