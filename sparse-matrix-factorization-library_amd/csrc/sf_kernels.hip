@@ -1062,6 +1062,9 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
     // different K (different source supernodes in one launch) no longer leave a workgroup idle while its neighbour works off a
     // round of long ones.  Head and tail are split statically as before.
     int ph = 0, rr = 0;
+#ifdef SF_EXP_DEPHASE
+    bool exp_dephased = false;
+#endif
 #ifdef SF_EXP_TIMING
     int exp_tile = 0;
     // per workgroup, behind the tile stamps: shader-clock and constant 100 MHz stamps at its first and last instruction
@@ -1089,6 +1092,15 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
         if (ti >= t1) continue;                 // (whole_tiles: the last round is partial)
         u = kt_prefix[ti];
         u_end = kt_prefix[ti + 1];
+#ifdef SF_EXP_DEPHASE           // experiment (round 4): the second workgroup of every CU (blockIdx >= grid / 2: the dispatcher fills the CUs
+        // round-robin) starts its first whole tile half a K loop late, so that the two co-resident workgroups do not sit in their
+        // prologues and atomic epilogues -- no MFMA work -- at the same time for the rest of the launch
+        if (!exp_dephased && blockIdx.x >= gridDim.x / 2) {
+            const int naps = (int)(u_end - u) * SF_EXP_DEPHASE / 16;       // one s_sleep 127 = 8128 cycles; a 16-deep K step of two workgroups ~ 8.5k
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+        exp_dephased = true;
+#endif
     } else {
         const uint32_t ra = (ph == 0) ? u_lo : tail_beg, rb = (ph == 0) ? head_end : u_hi;
         const uint32_t U = (rb > ra) ? (rb - ra + G - 1) / G : 0;

@@ -145,17 +145,23 @@ void build_triangles(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     t.join();
 }
 
+// The three graph passes below walk arrays of n entries at random (ancestor chains, child lists, disjoint sets): at n = 2M they are
+// bound by cache misses, so their WORK arrays are 32-bit whenever n allows (round 4; the results are the same integers, the reference's
+// Long arrays at the interface).  I = int32_t for n < 2^31, Long otherwise.
+
 // Liu's elimination tree with path compression over the rows of L (columns of L^T).
-void elimination_tree(const Symbolic& S, std::vector<Long>& Parent) {
+template <class I>
+void elimination_tree_t(const Symbolic& S, std::vector<Long>& Parent) {
     const Long n = S.n;
-    Parent.assign(n, -1);
-    std::vector<Long> Anc(n, -1);
-    auto climb = [&](Long i, Long j) {
-        while (i >= 0 && i < j) {
-            const Long a = Anc[i];
-            Anc[i] = j;
-            if (a < 0) { Parent[i] = j; break; }
-            if (a == j) break;
+    std::vector<I> Par(n, (I)-1), Anc(n, (I)-1);
+    auto climb = [&](Long i0, Long j) {
+        I i = (I)i0;
+        const I jj = (I)j;
+        while (i >= 0 && i < jj) {
+            const I a = Anc[i];
+            Anc[i] = jj;
+            if (a < 0) { Par[i] = jj; break; }
+            if (a == jj) break;
             i = a;
         }
     };
@@ -165,96 +171,108 @@ void elimination_tree(const Symbolic& S, std::vector<Long>& Parent) {
         if (both)
             for (Long p = S.UTp[j]; p < S.UTp[j + 1]; ++p) climb(S.UTi[p], j);
     }
+    Parent.resize(n);
+    for (Long j = 0; j < n; ++j) Parent[j] = Par[j];
+}
+void elimination_tree(const Symbolic& S, std::vector<Long>& Parent) {
+    if (S.n < (Long)0x7fffffff) elimination_tree_t<int32_t>(S, Parent); else elimination_tree_t<Long>(S, Parent);
 }
 
 // Postorder of the forest.  With weights (ColCount), children are visited in ascending weight,
 // ties in ascending index; without, in ascending index.  Roots in ascending index.
-void postorder(const std::vector<Long>& Parent, const std::vector<Long>* Weight, std::vector<Long>& Post) {
+// (The reference threads the children through linked lists filled from weight buckets, C:1175-1199; the visiting order that produces
+// is reproduced here with the children of every node laid out contiguously -- a counting sort by weight, then a stable distribution
+// to the parents -- so the depth-first walk reads child lists sequentially instead of chasing two pointers per child.)
+template <class I>
+void postorder_t(const std::vector<Long>& Parent, const std::vector<Long>* Weight, std::vector<Long>& Post) {
     const Long n = (Long)Parent.size();
-    std::vector<Long> Head(n, -1), Next(n, -1);
+    std::vector<I> order;                   // the non-root nodes in visiting order of siblings: ascending (weight, index)
+    order.reserve(n);
     if (!Weight) {
-        for (Long j = n - 1; j >= 0; --j) {
-            const Long p = Parent[j];
-            if (p >= 0 && p < n) { Next[j] = Head[p]; Head[p] = j; }
-        }
+        for (Long j = 0; j < n; ++j)
+            if (Parent[j] >= 0 && Parent[j] < n) order.push_back((I)j);
     } else {
-        // bucket by weight; the reference's buckets are [0,n) (C:1175-1199).  A weight of n (first
-        // column dense, not a root) would fall outside them there; we keep a bucket for it.
-        std::vector<Long> Bucket(n + 1, -1);
-        for (Long j = 0; j < n; ++j) {
-            if (Parent[j] >= 0) {
-                const Long w = (*Weight)[j];
-                Next[j] = Bucket[w];
-                Bucket[w] = j;
-            }
-        }
-        for (Long w = n; w >= 0; --w) {
-            Long j = Bucket[w];
-            while (j >= 0) {
-                const Long jn = Next[j];
-                const Long p = Parent[j];
-                Next[j] = Head[p];
-                Head[p] = j;
-                j = jn;
-            }
-        }
+        // weights lie in [0, n] (the reference's buckets are [0, n), C:1175-1199; a weight of n -- first column dense, not a root --
+        // would fall outside them there; a bucket is kept for it)
+        std::vector<I> start(n + 2, 0);
+        for (Long j = 0; j < n; ++j)
+            if (Parent[j] >= 0) start[(*Weight)[j] + 1]++;
+        for (Long w = 0; w <= n; ++w) start[w + 1] += start[w];
+        order.resize((size_t)start[n + 1]);
+        for (Long j = 0; j < n; ++j)
+            if (Parent[j] >= 0) order[(size_t)start[(*Weight)[j]]++] = (I)j;
     }
-    std::vector<Long> Stack;
-    Stack.reserve(n);
-    for (Long j = n - 1; j >= 0; --j)
-        if (Parent[j] < 0) Stack.push_back(j);
+    std::vector<I> cptr(n + 1, 0), child(order.size());
+    for (I j : order) cptr[Parent[j] + 1]++;
+    for (Long p = 0; p < n; ++p) cptr[p + 1] += cptr[p];
+    {
+        std::vector<I> fill(cptr.begin(), cptr.end() - 1);
+        for (I j : order) child[(size_t)fill[Parent[j]]++] = j;
+    }
+    std::vector<I> next(cptr.begin(), cptr.end() - 1);      // next child of a node on the stack
+    std::vector<I> Stack;
+    Stack.reserve(1024);
     Post.assign(n, -1);
     Long k = 0;
-    while (!Stack.empty()) {
-        const Long j = Stack.back();
-        const Long c = Head[j];
-        if (c >= 0) {
-            Head[j] = Next[c];
-            Stack.push_back(c);
-        } else {
-            Stack.pop_back();
-            Post[k++] = j;
+    for (Long r = 0; r < n; ++r) {
+        if (Parent[r] >= 0) continue;           // roots in ascending index
+        Stack.push_back((I)r);
+        while (!Stack.empty()) {
+            const I j = Stack.back();
+            if (next[j] < cptr[j + 1]) Stack.push_back(child[(size_t)next[j]++]);
+            else { Stack.pop_back(); Post[k++] = j; }
         }
     }
 }
+void postorder(const std::vector<Long>& Parent, const std::vector<Long>* Weight, std::vector<Long>& Post) {
+    if ((Long)Parent.size() < (Long)0x7ffffff0) postorder_t<int32_t>(Parent, Weight, Post); else postorder_t<Long>(Parent, Weight, Post);
+}
 
 // Column counts of L by the skeleton-leaf / disjoint-set method (C:1238-1352).
-void column_counts(const Symbolic& S, const std::vector<Long>& Parent, const std::vector<Long>& Post,
-                   std::vector<Long>& Count) {
+template <class I>
+void column_counts_t(const Symbolic& S, const std::vector<Long>& Parent, const std::vector<Long>& Post,
+                     std::vector<Long>& Count) {
     const Long n = S.n;
-    std::vector<Long> First(n, -1), Set(n), PrevLeaf(n), PrevNbr(n, -1);
-    Count.assign(n, 0);
+    std::vector<I> Par(n), First(n, (I)-1), Set(n), PrevLeaf(n), PrevNbr(n, (I)-1), Cnt(n, 0);
+    for (Long j = 0; j < n; ++j) Par[j] = (I)Parent[j];
     for (Long k = 0; k < n; ++k) {
-        for (Long p = Post[k]; p >= 0 && First[p] < 0; p = Parent[p]) First[p] = k;
+        for (I p = (I)Post[k]; p >= 0 && First[p] < 0; p = Par[p]) First[p] = (I)k;
     }
-    for (Long j = 0; j < n; ++j) { Set[j] = j; PrevLeaf[j] = j; }
+    for (Long j = 0; j < n; ++j) { Set[j] = (I)j; PrevLeaf[j] = (I)j; }
     const bool both = S.lu && !S.symmetric;     // LU: counts of the pattern of L + U^T (L:1601-1625)
     for (Long k = 0; k < n; ++k) {
-        const Long j = Post[k];
-        PrevNbr[j] = k;
-        auto visit = [&](Long i) {
+        const I j = (I)Post[k];
+        PrevNbr[j] = (I)k;
+        auto visit = [&](Long i0) {
+            const I i = (I)i0;
             if (i <= j) return;
             if (First[j] > PrevNbr[i]) {
-                const Long pl = PrevLeaf[i];
-                Long r = pl;
+                const I pl = PrevLeaf[i];
+                I r = pl;
                 while (r != Set[r]) r = Set[r];
-                for (Long s = pl; s != r;) { const Long t = Set[s]; Set[s] = r; s = t; }
-                Count[j]++;
-                Count[r]--;
+                for (I s = pl; s != r;) { const I t = Set[s]; Set[s] = r; s = t; }
+                Cnt[j]++;
+                Cnt[r]--;
                 PrevLeaf[i] = j;
             }
-            PrevNbr[i] = k;
+            PrevNbr[i] = (I)k;
         };
         for (Long p = S.Lp[j]; p < S.Lp[j + 1]; ++p) visit(S.Li[p]);
         if (both)
             for (Long p = S.Up[j]; p < S.Up[j + 1]; ++p) visit(S.Ui[p]);
-        Set[j] = Parent[j];
+        Set[j] = Par[j];
     }
+    Count.assign(n, 0);
     for (Long k = 0; k < n; ++k) {
-        const Long j = Post[k];
-        if (Parent[j] >= 0) Count[Parent[j]] += Count[j];
+        const I j = (I)Post[k];
+        if (Par[j] >= 0) Cnt[Par[j]] += Cnt[j];
     }
-    for (Long j = 0; j < n; ++j) Count[j]++;
+    for (Long j = 0; j < n; ++j) Count[j] = (Long)Cnt[j] + 1;
+}
+void column_counts(const Symbolic& S, const std::vector<Long>& Parent, const std::vector<Long>& Post,
+                   std::vector<Long>& Count) {
+    // (32-bit work arrays: the intermediate counts stay within +-n and the final ones are at most n)
+    if (S.n < (Long)0x7ffffff0) column_counts_t<int32_t>(S, Parent, Post, Count); else column_counts_t<Long>(S, Parent, Post, Count);
 }
 
 // number of values of a panel with ncol columns and nrow rows in its row list:
@@ -710,30 +728,33 @@ namespace {
 // caller does the second: same permutation as the sequential code, whatever the thread count.  mark[] is read across pieces (a
 // neighbour in another piece) while its owner may be renumbering it: those accesses are relaxed atomics, and the only thing a
 // reader asks is "is it MY id", which no other piece's id ever equals.
+// vertex ids, piece ids and BFS levels are 32-bit inside the dissection (n < 2^30, checked by graph_nd_perm): the sweeps are bound by
+// memory traffic over the adjacency, mark and level arrays, and halving them is a quarter of the ordering's time (round 4)
+using Vx = int32_t;
 struct NdCtx {
     const std::vector<Long>& Ap;
-    const std::vector<Long>& Ai;
-    std::vector<Long> mark;      // mark[v] = id of the piece v currently belongs to
-    std::vector<Long> level;
+    const std::vector<Vx>& Ai;
+    std::vector<Vx> mark;      // mark[v] = id of the piece v currently belongs to
+    std::vector<Vx> level;
     Long* out;
-    Long leaf;
-    std::atomic<Long> next_id{1};
+    Vx leaf;
+    std::atomic<Vx> next_id{1};
     std::atomic<int> helpers{0};
     int max_helpers = 0;
-    Long mk(Long v) const { return __atomic_load_n(&mark[v], __ATOMIC_RELAXED); }
-    void set_mk(Long v, Long id) { __atomic_store_n(&mark[v], id, __ATOMIC_RELAXED); }
+    Vx mk(Vx v) const { return __atomic_load_n(&mark[v], __ATOMIC_RELAXED); }
+    void set_mk(Vx v, Vx id) { __atomic_store_n(&mark[v], id, __ATOMIC_RELAXED); }
 };
 
 // BFS inside piece `id` from `root`; returns the vertices in BFS order and fills level[]
-void nd_bfs(NdCtx& c, Long id, Long root, std::vector<Long>& order) {
+void nd_bfs(NdCtx& c, Vx id, Vx root, std::vector<Vx>& order) {
     order.clear();
     order.push_back(root);
     c.level[root] = 0;
     c.set_mk(root, -2 - id);        // visited: -2 - id (unique to the piece as well)
     for (size_t h = 0; h < order.size(); ++h) {
-        const Long v = order[h];
+        const Vx v = order[h];
         for (Long p = c.Ap[v]; p < c.Ap[v + 1]; ++p) {
-            const Long w = c.Ai[p];
+            const Vx w = c.Ai[p];
             if (c.mk(w) == id) {
                 c.set_mk(w, -2 - id);
                 c.level[w] = c.level[v] + 1;
@@ -741,11 +762,11 @@ void nd_bfs(NdCtx& c, Long id, Long root, std::vector<Long>& order) {
             }
         }
     }
-    for (Long v : order) c.set_mk(v, id);    // restore
+    for (Vx v : order) c.set_mk(v, id);    // restore
 }
 
-void nd_component(NdCtx& c, std::vector<Long>& comp, Long pos);
-void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team);
+void nd_component(NdCtx& c, std::vector<Vx>& comp, Vx pos);
+void nd_recurse(NdCtx& c, std::vector<Vx>& verts, Vx pos, int team);
 
 // ---- big pieces: the BFS itself is shared by a TEAM of threads -------------------------------------------------------------------
 // At the top of the dissection there are 1, 2, 4, ... pieces: one thread per piece leaves the other threads idle exactly where the
@@ -755,7 +776,7 @@ void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team);
 // level of every vertex, the level sets and the smallest vertex of the last level are the same for any team size, the restart root
 // is that smallest vertex, and the vertex lists handed down are kept sorted by vertex number (a filter of a sorted list).  A piece
 // takes this path or the sequential one by its SIZE alone, so the permutation does not depend on the number of threads.
-constexpr Long ND_PAR_MIN = 100000;
+constexpr Vx ND_PAR_MIN = 100000;
 
 struct SpinBarrier {
     std::atomic<int> cnt{0}, gen{0};
@@ -770,40 +791,40 @@ struct SpinBarrier {
 // BFS of piece `id` from `root` by `team` threads.  order: the visited vertices, level by level (capacity `cap` >= piece size);
 // level[] filled; the marks of the visited vertices end as `final_mark`.  Returns the number of levels; *last_min = smallest vertex
 // of the last level.
-Long nd_bfs_team(NdCtx& c, Long id, Long root, int team, Long cap, Long final_mark, std::vector<Long>& order, Long* last_min) {
+Vx nd_bfs_team(NdCtx& c, Vx id, Vx root, int team, Vx cap, Vx final_mark, std::vector<Vx>& order, Vx* last_min) {
     team = std::max(1, team);
     order.assign((size_t)cap, 0);
-    const Long vis = -2 - id;
+    const Vx vis = -2 - id;
     order[0] = root;
     c.level[root] = 0;
     c.set_mk(root, vis);
-    Long lo = 0, hi = 1, lev = 0;                       // frontier = order[lo, hi): written by thread 0 between barriers
-    std::vector<std::vector<Long>> local((size_t)team);
-    std::vector<Long> sizes((size_t)team, 0);
+    Vx lo = 0, hi = 1, lev = 0;                       // frontier = order[lo, hi): written by thread 0 between barriers
+    std::vector<std::vector<Vx>> local((size_t)team);
+    std::vector<Vx> sizes((size_t)team, 0);
     SpinBarrier bar;
     bar.n = team;
     bool done = false;
     auto body = [&](int t) {
-        std::vector<Long>& mine = local[(size_t)t];
+        std::vector<Vx>& mine = local[(size_t)t];
         for (;;) {
-            const Long F = hi - lo;
-            const Long a = lo + F * t / team, b = lo + F * (t + 1) / team;
+            const Vx F = hi - lo;
+            const Vx a = lo + F * t / team, b = lo + F * (t + 1) / team;
             mine.clear();
-            for (Long h = a; h < b; ++h) {
-                const Long v = order[(size_t)h];
+            for (Vx h = a; h < b; ++h) {
+                const Vx v = order[(size_t)h];
                 for (Long p = c.Ap[v]; p < c.Ap[v + 1]; ++p) {
-                    const Long w = c.Ai[p];
+                    const Vx w = c.Ai[p];
                     if (c.mk(w) != id) continue;
-                    Long expect = id;
+                    Vx expect = id;
                     if (__atomic_compare_exchange_n(&c.mark[w], &expect, vis, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
                         c.level[w] = lev + 1;
                         mine.push_back(w);
                     }
                 }
             }
-            sizes[(size_t)t] = (Long)mine.size();
+            sizes[(size_t)t] = (Vx)mine.size();
             bar.wait();
-            Long off = hi, total = 0;
+            Vx off = hi, total = 0;
             for (int q = 0; q < team; ++q) { if (q < t) off += sizes[(size_t)q]; total += sizes[(size_t)q]; }
             for (size_t k = 0; k < mine.size(); ++k) order[(size_t)off + k] = mine[k];
             bar.wait();
@@ -820,13 +841,13 @@ Long nd_bfs_team(NdCtx& c, Long id, Long root, int team, Long cap, Long final_ma
     body(0);
     for (std::thread& x : th) x.join();
     order.resize((size_t)hi);
-    Long mn = order[(size_t)lo];
-    for (Long h = lo; h < hi; ++h) mn = std::min(mn, order[(size_t)h]);
+    Vx mn = order[(size_t)lo];
+    for (Vx h = lo; h < hi; ++h) mn = std::min(mn, order[(size_t)h]);
     *last_min = mn;
     // marks: visited -> final_mark (split among the team)
     {
-        const Long N = hi;
-        auto fin = [&](int t) { for (Long h = N * t / team; h < N * (t + 1) / team; ++h) c.set_mk(order[(size_t)h], final_mark); };
+        const Vx N = hi;
+        auto fin = [&](int t) { for (Vx h = N * t / team; h < N * (t + 1) / team; ++h) c.set_mk(order[(size_t)h], final_mark); };
         std::vector<std::thread> th2;
         for (int t = 1; t < team; ++t) th2.emplace_back(fin, t);
         fin(0);
@@ -837,39 +858,39 @@ Long nd_bfs_team(NdCtx& c, Long id, Long root, int team, Long cap, Long final_ma
 
 // one connected big piece: `comp` sorted by vertex number, all marked with one id; `root`: where the level structure starts (the
 // smallest vertex of the last level of the sweep that found the component = the second sweep of a pseudo-peripheral search)
-void nd_component_big(NdCtx& c, std::vector<Long>& comp, Long pos, int team, Long root) {
-    const Long id = c.mk(comp[0]);
-    std::vector<Long> order;
-    Long last_min = 0;
-    const Long nlev = nd_bfs_team(c, id, root, team, (Long)comp.size(), id, order, &last_min);
-    { std::vector<Long>().swap(order); }
+void nd_component_big(NdCtx& c, std::vector<Vx>& comp, Vx pos, int team, Vx root) {
+    const Vx id = c.mk(comp[0]);
+    std::vector<Vx> order;
+    Vx last_min = 0;
+    const Vx nlev = nd_bfs_team(c, id, root, team, (Vx)comp.size(), id, order, &last_min);
+    { std::vector<Vx>().swap(order); }
     if (nlev < 3) {         // (nearly) complete graph: no useful separator
-        for (Long v : comp) { c.out[pos++] = v; c.set_mk(v, -1); }
+        for (Vx v : comp) { c.out[pos++] = v; c.set_mk(v, -1); }
         return;
     }
-    std::vector<Long> cnt((size_t)nlev, 0);
-    for (Long v : comp) cnt[(size_t)c.level[v]]++;
-    Long best = 1, best_cost = -1, below = cnt[0], below0 = cnt[0];
-    const Long total = (Long)comp.size();
-    for (Long l = 1; l + 1 < nlev; ++l) {
-        const Long above = total - below - cnt[(size_t)l];
-        const Long cost = std::max(below, above) + cnt[(size_t)l];
+    std::vector<Vx> cnt((size_t)nlev, 0);
+    for (Vx v : comp) cnt[(size_t)c.level[v]]++;
+    Vx best = 1, best_cost = -1, below = cnt[0], below0 = cnt[0];
+    const Vx total = (Vx)comp.size();
+    for (Vx l = 1; l + 1 < nlev; ++l) {
+        const Vx above = total - below - cnt[(size_t)l];
+        const Vx cost = std::max(below, above) + cnt[(size_t)l];
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = l; below0 = below; }
         below += cnt[(size_t)l];
     }
-    std::vector<Long> A, B, Sep;
-    const Long ida = c.next_id++, idb = c.next_id++;
+    std::vector<Vx> A, B, Sep;
+    const Vx ida = c.next_id++, idb = c.next_id++;
     A.reserve((size_t)below0);
     B.reserve((size_t)(total - below0 - cnt[(size_t)best]));
     Sep.reserve((size_t)cnt[(size_t)best]);
-    for (Long v : comp) {                                   // sorted in, sorted out
+    for (Vx v : comp) {                                   // sorted in, sorted out
         if (c.level[v] < best) { A.push_back(v); c.set_mk(v, ida); }
         else if (c.level[v] > best) { B.push_back(v); c.set_mk(v, idb); }
         else Sep.push_back(v);
     }
-    for (Long v : Sep) c.set_mk(v, -1);
-    { std::vector<Long>().swap(comp); }
-    const Long posA = pos, posB = pos + (Long)A.size(), posS = posB + (Long)B.size();
+    for (Vx v : Sep) c.set_mk(v, -1);
+    { std::vector<Vx>().swap(comp); }
+    const Vx posA = pos, posB = pos + (Vx)A.size(), posS = posB + (Vx)B.size();
     const int team_a = std::max(1, team / 2), team_b = std::max(1, team - team_a);
     std::thread helper;
     if (!A.empty() && !B.empty() && team >= 2) {
@@ -878,8 +899,8 @@ void nd_component_big(NdCtx& c, std::vector<Long>& comp, Long pos, int team, Lon
     } else if (!A.empty()) nd_recurse(c, A, posA, team);
     if (!B.empty()) nd_recurse(c, B, posB, helper.joinable() ? team_b : team);
     if (helper.joinable()) { helper.join(); c.helpers.fetch_sub(1); }
-    Long q = posS;
-    for (Long v : Sep) c.out[q++] = v;
+    Vx q = posS;
+    for (Vx v : Sep) c.out[q++] = v;
 }
 
 
@@ -892,47 +913,47 @@ void nd_component_big(NdCtx& c, std::vector<Long>& comp, Long pos, int team, Lon
 //     whole-piece filter and 2 (team - 1) thread starts PER COMPONENT: a piece of 10^5 vertices with many small components -- the
 //     identity rows of a finite-element matrix, a diagonal matrix -- went quadratic: n = 104,000 diagonal 34 s)
 // Which path a component takes depends on sizes and vertex numbers only, never on the number of threads.
-void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team) {
-    const Long id = c.mk(verts[0]);
-    if ((Long)verts.size() >= ND_PAR_MIN) {
-        std::vector<Long> order;
-        Long last_min = 0;
-        const Long cid = c.next_id++;
-        (void)nd_bfs_team(c, id, verts[0], team, (Long)verts.size(), cid, order, &last_min);
-        const Long found = (Long)order.size();
-        { std::vector<Long>().swap(order); }
-        if (found == (Long)verts.size()) { nd_component_big(c, verts, pos, team, last_min); return; }
-        std::vector<Long> comp;
+void nd_recurse(NdCtx& c, std::vector<Vx>& verts, Vx pos, int team) {
+    const Vx id = c.mk(verts[0]);
+    if ((Vx)verts.size() >= ND_PAR_MIN) {
+        std::vector<Vx> order;
+        Vx last_min = 0;
+        const Vx cid = c.next_id++;
+        (void)nd_bfs_team(c, id, verts[0], team, (Vx)verts.size(), cid, order, &last_min);
+        const Vx found = (Vx)order.size();
+        { std::vector<Vx>().swap(order); }
+        if (found == (Vx)verts.size()) { nd_component_big(c, verts, pos, team, last_min); return; }
+        std::vector<Vx> comp;
         comp.reserve((size_t)found);
-        for (Long v : verts)
+        for (Vx v : verts)
             if (c.mk(v) == cid) comp.push_back(v);              // sorted in, sorted out
         if (found >= ND_PAR_MIN) nd_component_big(c, comp, pos, team, last_min);
         else {
             // the sequential code wants the component in BFS order from some vertex of it (the team's order inside a level is a race)
-            std::vector<Long> o2;
+            std::vector<Vx> o2;
             nd_bfs(c, cid, comp[0], o2);
             nd_component(c, o2, pos);
         }
         pos += found;
     }
-    std::vector<Long> comp;
-    for (Long v : verts) {
+    std::vector<Vx> comp;
+    for (Vx v : verts) {
         if (c.mk(v) != id) continue;          // already ordered as part of an earlier component
         nd_bfs(c, id, v, comp);
-        const Long cid = c.next_id++;
-        for (Long w : comp) c.set_mk(w, cid);
-        const Long sz = (Long)comp.size();
+        const Vx cid = c.next_id++;
+        for (Vx w : comp) c.set_mk(w, cid);
+        const Vx sz = (Vx)comp.size();
         if (sz >= ND_PAR_MIN) {
             // a big component behind smaller ones: level structure from the smallest vertex of the last level of this sweep (what the
             // team's sweep would have reported), vertex list sorted by a filter of the piece's
-            const Long last = c.level[comp.back()];
-            Long root = comp.back();
+            const Vx last = c.level[comp.back()];
+            Vx root = comp.back();
             for (size_t k = comp.size(); k-- > 0 && c.level[comp[k]] == last;) root = std::min(root, comp[k]);
-            std::vector<Long> sorted;
+            std::vector<Vx> sorted;
             sorted.reserve((size_t)sz);
-            for (Long w : verts)
+            for (Vx w : verts)
                 if (c.mk(w) == cid) sorted.push_back(w);
-            { std::vector<Long>().swap(comp); }
+            { std::vector<Vx>().swap(comp); }
             nd_component_big(c, sorted, pos, team, root);
         } else {
             nd_component(c, comp, pos);
@@ -942,56 +963,59 @@ void nd_recurse(NdCtx& c, std::vector<Long>& verts, Long pos, int team) {
 }
 
 // one connected piece, all vertices marked with one id; `comp` is in BFS order from some vertex of it; output range out[pos, pos + |comp|)
-void nd_component(NdCtx& c, std::vector<Long>& comp, Long pos) {
-    std::vector<Long>& verts = comp;
-    const Long id = c.mk(verts[0]);
-    if ((Long)verts.size() <= c.leaf) {
+void nd_component(NdCtx& c, std::vector<Vx>& comp, Vx pos) {
+    std::vector<Vx>& verts = comp;
+    const Vx id = c.mk(verts[0]);
+    if ((Vx)verts.size() <= c.leaf) {
         // BFS order from a pseudo-peripheral vertex, reversed
-        std::vector<Long> o2;
+        std::vector<Vx> o2;
         nd_bfs(c, id, comp.back(), o2);
         for (size_t k = o2.size(); k-- > 0;) { c.out[pos++] = o2[k]; c.set_mk(o2[k], -1); }
         return;
     }
     // pseudo-peripheral root: restart the BFS from the last vertex of the previous one
-    std::vector<Long> order;
+    std::vector<Vx> order;
     nd_bfs(c, id, comp.back(), order);
-    const Long nlev = c.level[order.back()] + 1;
+    const Vx nlev = c.level[order.back()] + 1;
     if (nlev < 3) {     // (nearly) complete graph: no useful separator
         for (size_t k = order.size(); k-- > 0;) { c.out[pos++] = order[k]; c.set_mk(order[k], -1); }
         return;
     }
-    std::vector<Long> cnt(nlev, 0);
-    for (Long v : order) cnt[c.level[v]]++;
+    std::vector<Vx> cnt(nlev, 0);
+    for (Vx v : order) cnt[c.level[v]]++;
     // separator level: minimise max(|below|, |above|) + |level| over interior levels
-    Long best = 1, best_cost = -1, below = cnt[0];
-    const Long total = (Long)order.size();
-    for (Long l = 1; l + 1 < nlev; ++l) {
-        const Long above = total - below - cnt[l];
-        const Long cost = std::max(below, above) + cnt[l];
+    Vx best = 1, best_cost = -1, below = cnt[0];
+    const Vx total = (Vx)order.size();
+    for (Vx l = 1; l + 1 < nlev; ++l) {
+        const Vx above = total - below - cnt[l];
+        const Vx cost = std::max(below, above) + cnt[l];
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = l; }
         below += cnt[l];
     }
-    std::vector<Long> A, B, Sep;
-    const Long ida = c.next_id++, idb = c.next_id++;
-    for (Long v : order) {
+    std::vector<Vx> A, B, Sep;
+    const Vx ida = c.next_id++, idb = c.next_id++;
+    for (Vx v : order) {
         if (c.level[v] < best) { A.push_back(v); c.set_mk(v, ida); }
         else if (c.level[v] > best) { B.push_back(v); c.set_mk(v, idb); }
         else Sep.push_back(v);
     }
-    for (Long v : Sep) c.set_mk(v, -1);       // removed from the graph for the recursion
-    { std::vector<Long>().swap(order); std::vector<Long>().swap(comp); }
-    const Long posA = pos, posB = pos + (Long)A.size(), posS = posB + (Long)B.size();
+    for (Vx v : Sep) c.set_mk(v, -1);       // removed from the graph for the recursion
+    { std::vector<Vx>().swap(order); std::vector<Vx>().swap(comp); }
+    const Vx posA = pos, posB = pos + (Vx)A.size(), posS = posB + (Vx)B.size();
+    // A (the levels below the separator) is CONNECTED -- every vertex hangs on the BFS tree of the root -- and already listed in BFS order
+    // from that root: exactly what nd_recurse's component sweep from A[0] would find and hand to nd_component, so it goes there at once
+    // (the same permutation as before, one sweep over half of every piece less).  B may fall apart: it is swept.
     std::thread helper;
-    if (!A.empty() && !B.empty() && (Long)A.size() >= 20000 && c.helpers.fetch_add(1) < c.max_helpers)
-        helper = std::thread([&c, &A, posA] { nd_recurse(c, A, posA, 1); });
+    if (!A.empty() && !B.empty() && (Vx)A.size() >= 20000 && c.helpers.fetch_add(1) < c.max_helpers)
+        helper = std::thread([&c, &A, posA] { nd_component(c, A, posA); });
     else {
-        if (!A.empty() && !B.empty() && (Long)A.size() >= 20000) c.helpers.fetch_sub(1);      // no free helper: undo the claim
-        if (!A.empty()) nd_recurse(c, A, posA, 1);
+        if (!A.empty() && !B.empty() && (Vx)A.size() >= 20000) c.helpers.fetch_sub(1);      // no free helper: undo the claim
+        if (!A.empty()) nd_component(c, A, posA);
     }
     if (!B.empty()) nd_recurse(c, B, posB, 1);
     if (helper.joinable()) { helper.join(); c.helpers.fetch_sub(1); }
-    Long q = posS;
-    for (Long v : Sep) c.out[q++] = v;
+    Vx q = posS;
+    for (Vx v : Sep) c.out[q++] = v;
 }
 }  // namespace
 
@@ -1001,7 +1025,9 @@ int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm)
     const bool tr_nd = getenv("SF_TRACE") != nullptr;
     auto now_nd = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_nd0 = now_nd();
-    std::vector<Long> Ap(n + 1, 0), Ai;
+    if (n >= ((Long)1 << 30)) return 1;          // 32-bit vertex and piece ids inside the dissection
+    std::vector<Long> Ap(n + 1, 0);
+    std::vector<Vx> Ai;
     for (Long j = 0; j < n; ++j)
         for (Long p = Cp[j]; p < Cp[j + 1]; ++p) {
             const Long i = Ci[p];
@@ -1015,15 +1041,15 @@ int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm)
         for (Long j = 0; j < n; ++j)
             for (Long p = Cp[j]; p < Cp[j + 1]; ++p) {
                 const Long i = Ci[p];
-                if (i != j) { Ai[fill[i]++] = j; Ai[fill[j]++] = i; }
+                if (i != j) { Ai[fill[i]++] = (Vx)j; Ai[fill[j]++] = (Vx)i; }
             }
     }
     const double t_nd1 = now_nd();
-    NdCtx c{Ap, Ai, std::vector<Long>(n, 0), std::vector<Long>(n, 0), perm, leaf};
+    NdCtx c{Ap, Ai, std::vector<Vx>(n, 0), std::vector<Vx>(n, 0), perm, (Vx)std::min<Long>(leaf, n)};
     c.max_helpers = analysis_threads() - 1;
     if (n == 0) return 0;
-    std::vector<Long> all(n);
-    for (Long v = 0; v < n; ++v) all[v] = v;
+    std::vector<Vx> all(n);
+    for (Long v = 0; v < n; ++v) all[v] = (Vx)v;
     for (Long v = 0; v < n; ++v) perm[v] = -1;
     nd_recurse(c, all, 0, analysis_threads());    // recursion depth = dissection depth, O(log n) for balanced level separators
     if (tr_nd) fprintf(stderr, "[sparseframe-hip]   ordering: adjacency %.1f ms, dissection %.1f ms (%d threads)\n", t_nd1 - t_nd0, now_nd() - t_nd1, analysis_threads());
