@@ -8,6 +8,7 @@ The reference cannot run in this image and ships no fixtures, so the values come
 and are accepted only after agreeing with something that shares no code with it:
   chol_lap3d_24        dense LAPACK Cholesky of the permuted matrix (numpy), 1e-12
   chol_stencil2d_200   SuperLU (scipy.sparse.linalg.splu, natural order, no pivoting, symmetric mode): L sqrt(diag U), 1e-12
+  nopiv_lu_stencil_16  SuperLU in natural order without pivoting: the packed L \ U panels entry by entry, 1e-12 (the reference's LU never pivots)
   piv_dense_200_tol01  the numpy statement of the block-restricted threshold rule (tests/test_lu_pivot_oracle.py), pivots exact
   piv_zero_diag_12     the solve with the recorded interchanges against SuperLU's solution of the same system
 The pivoting rule is the product's own (the reference never pivots: LU/Source/SparseFrame.c:2653, :3344): PARITY UNPINNED by
@@ -89,6 +90,30 @@ def main():
             rec["accepted_by"] = f"{how}: max rel err {err:.2e}"
             diag_idx = np.asarray(S.Lsxp)[:-1][np.asarray(S.SuperMap)] + \
                 (np.arange(n) - np.asarray(S.Super)[np.asarray(S.SuperMap)]) * (np.diff(S.Lsip)[np.asarray(S.SuperMap)] + 1)
+        elif name == "nopiv_lu_stencil_16":
+            # the reference's own LU behaviour (no pivoting): accepted against SuperLU in natural order with diag_pivot_thresh = 0
+            # (it keeps the diagonal pivots of this diagonally dominant matrix: perm_r = identity is asserted), entry by entry of the
+            # packed panels (L:2514-2517: rows [0, nscol) = L11 \ U11, [nscol, nsrow) = L21, [nsrow, 2 nsrow - nscol) = U12^T)
+            oracle.blas_init("auto", threads=4)
+            Lsx, info, _ = oracle.lu_factorize(S)
+            oracle.blas_init("builtin")
+            assert info == 0
+            mask = np.ones(S.xsize, dtype=bool)
+            Ap = sp.csc_matrix((c["Cx"], c["Ci"], c["Cp"]), shape=(n, n))[S.Perm][:, S.Perm].tocsc()
+            lu = spla.splu(Ap, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+            assert np.array_equal(lu.perm_r, np.arange(n)) and np.array_equal(lu.perm_c, np.arange(n))
+            Lm, Um = lu.L.tocsr(), lu.U.tocsr()
+            r, col, upper = panel_positions(S, lu=True)
+            inblock_upper = ~upper & (r <= col)                     # U11 (diagonal included) sits in the L11 rows of the packed panel
+            want = np.where(upper, np.asarray(Um[col, r]).ravel(),                                  # U12^T: U(column, row')
+                            np.where(inblock_upper, np.asarray(Um[r, col]).ravel(), np.asarray(Lm[r, col]).ravel()))
+            err = rel_err(Lsx, want, mask)
+            assert err <= 1e-12, (name, err)
+            rec["accepted_by"] = f"SuperLU (scipy splu, natural order, no pivoting): packed L \\ U panels, max rel err {err:.2e}"
+            rec.update(pivpos=None, perturbed=0)
+            Xp = np.asarray(S.Lsxp)[:-1]
+            sm = np.asarray(S.SuperMap)
+            diag_idx = Xp[sm] + (np.arange(n) - np.asarray(S.Super)[sm]) * (2 * np.diff(S.Lsip)[sm] - np.diff(S.Super)[sm] + 1)
         else:
             tol = rec["tol"]
             Lsx, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=tol)

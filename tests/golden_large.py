@@ -10,7 +10,7 @@ import numpy as np
 from util import sf, gen, nd_perm_py
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = ("chol_lap3d_24", "chol_stencil2d_200", "piv_dense_200_tol01", "piv_zero_diag_12")
+CASES = ("chol_lap3d_24", "chol_stencil2d_200", "nopiv_lu_stencil_16", "piv_dense_200_tol01", "piv_zero_diag_12")
 
 
 def sha(a):
@@ -33,6 +33,11 @@ def build_case(name):
         n, Cp, Ci, Cx = gen.stencil_spd_lower(200, 200)
         perm, slot, method, symm = sf.grid_nd_perm(200, 200, 1, 3, 2), sf.REFERENCE_SLOT_1GPU, "cholesky", True
         spec = dict(generator="stencil_spd_lower(200, 200)", ordering="grid_nd_perm(200, 200, 1, leaf 3, separator width 2)")
+    elif name == "nopiv_lu_stencil_16":  # the reference's LU (no pivoting, L:2653): unsymmetric 19-point stencil, root of > 1000 columns
+        N = 16
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=13)
+        perm, slot, method, symm = nd_perm_py(N, N, N), 1 << 30, "lu", False
+        spec = dict(generator="unsymmetric_stencil(16, 16, 16, seed=13)", ordering="nd_perm_py(16, 16, 16)", tol=0.0)
     elif name == "piv_dense_200_tol01":  # one front of four 64-column blocks
         A = np.random.default_rng(11).uniform(-1, 1, (200, 200))
         n = 200

@@ -327,11 +327,13 @@ def test_lu_golden_fixtures():
 
 
 @pytest.mark.parametrize("fuse", ["", "0"], ids=["fused_step", "three_launches"])
-@pytest.mark.parametrize("name", ["piv_dense_200_tol01", "piv_zero_diag_12"])
+@pytest.mark.parametrize("name", ["nopiv_lu_stencil_16", "piv_dense_200_tol01", "piv_zero_diag_12"])
 def test_lu_golden_fixtures_large(name, fuse, monkeypatch):
-    """tests/golden/large_sampled.json: a pivoted front of four 64-column blocks (accepted against the numpy statement of the block
-    rule) and a pivoted sparse factorization with a 666-column root (accepted by its solve against SuperLU's): full pivot sequence,
-    perturbation count, sampled factor entries, sum log|pivots|, sum |entries|.  No oracle code runs here."""
+    """tests/golden/large_sampled.json: the reference's own LU behaviour (NO pivoting) on an unsymmetric 16^3 stencil with a
+    1340-column root (accepted entry by entry against SuperLU in natural order without pivoting), a pivoted front of four 64-column
+    blocks (accepted against the numpy statement of the block rule) and a pivoted sparse factorization with a 666-column root
+    (accepted by its solve against SuperLU's): full pivot sequence, perturbation count, sampled factor entries, sum log|pivots|,
+    sum |entries|.  No oracle code runs here."""
     import golden_large as GL
     if fuse:
         monkeypatch.setenv("SF_FUSE_MAX", fuse)
@@ -341,9 +343,10 @@ def test_lu_golden_fixtures_large(name, fuse, monkeypatch):
     S = c["sym"]
     plan = sf.LUPlan(S)
     plan.set_values(S.Lx, S.Ux)
-    plan.set_pivoting(g["tol"])
+    plan.set_pivoting(g["tol"], 0.0 if g["tol"] == 0.0 else 1.4901161193847656e-08)
     plan.factorize()
-    assert np.array_equal(plan.get_pivots(), np.asarray(g["pivpos"])), name
+    want_piv = np.arange(g["n"]) if g["pivpos"] is None else np.asarray(g["pivpos"])      # no pivoting (the reference's LU): identity
+    assert np.array_equal(plan.get_pivots(), want_piv), name
     assert int(plan.stat("perturbed_pivots")) == g["perturbed"]
     GL.check_factor(name, g, S, plan.get_factor(), 1e-11)
     plan.close()

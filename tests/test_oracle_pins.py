@@ -93,7 +93,7 @@ def test_numeric_against_dense_lapack(oracle, case, blas):
     oracle.blas_init("auto", threads=4)
 
 
-@pytest.mark.parametrize("name", ["chol_lap3d_24", "chol_stencil2d_200", "piv_dense_200_tol01", "piv_zero_diag_12"])
+@pytest.mark.parametrize("name", ["chol_lap3d_24", "chol_stencil2d_200", "nopiv_lu_stencil_16", "piv_dense_200_tol01", "piv_zero_diag_12"])
 def test_oracle_against_the_large_sampled_fixtures(oracle, name):
     """the oracle (threaded BLAS back end; the fixtures were made with its built-in loops) against tests/golden/large_sampled.json,
     whose values were accepted against dense LAPACK / SuperLU / the numpy block rule (tests/golden/make_golden_large.py)"""
@@ -105,6 +105,10 @@ def test_oracle_against_the_large_sampled_fixtures(oracle, name):
     oracle.blas_init("auto", threads=4)
     if g["method"] == "cholesky":
         Lsx, info, _ = oracle.chol_factorize(S)
+        assert info == 0
+        GL.check_factor(name, g, S, Lsx, 1e-12)
+    elif g["pivpos"] is None:
+        Lsx, info, _ = oracle.lu_factorize(S)                 # the no-pivot path (the reference's behaviour, L:2653)
         assert info == 0
         GL.check_factor(name, g, S, Lsx, 1e-12)
     else:
