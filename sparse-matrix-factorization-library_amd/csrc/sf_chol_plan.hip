@@ -209,15 +209,41 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     const size_t xb_factor = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double);
     hipError_t factor_alloc_err = hipSuccess;
     double* factor_mem = nullptr;           // handed to the plan once everything else has succeeded; freed by the guard otherwise
-    std::thread factor_alloc([&factor_alloc_err, &factor_mem, xb_factor, device, dry] {
+    // ... and, behind the allocation, the device copies of the symbolic structure (narrowed to 32-bit indices on the way): 150 MB of
+    // host loops and pageable H2D copies at 128^3 that depend on the inputs only, i.e. ~35 ms of the first call of a pattern that now
+    // run beside the validation and the task tables instead of after them (round 4)
+    struct EarlyUploads {
+        int64_t *d_Lp = nullptr, *d_Lsip = nullptr, *d_Lsxp = nullptr;
+        int32_t *d_Li = nullptr, *d_Super = nullptr, *d_SuperMap = nullptr, *d_Lsi = nullptr;
+        size_t bytes = 0;
+        int rc = SF_OK;
+        void release() {
+            void* q[] = {d_Lp, d_Lsip, d_Lsxp, d_Li, d_Super, d_SuperMap, d_Lsi};
+            for (void* x : q) if (x) (void)hipFree(x);
+            d_Lp = d_Lsip = d_Lsxp = nullptr; d_Li = d_Super = d_SuperMap = d_Lsi = nullptr;
+        }
+    } early;
+    const sf_long nnz_in = Lp[n], isize_in = Lsip[nsuper];
+    std::thread factor_alloc([&factor_alloc_err, &factor_mem, &early, xb_factor, device, dry, n, nsuper, nnz_in, isize_in, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li] {
         if (dry) return;
         factor_alloc_err = hipSetDevice(device);
         if (factor_alloc_err == hipSuccess) factor_alloc_err = hipMalloc((void**)&factor_mem, xb_factor);
+        if (factor_alloc_err != hipSuccess) return;
+        auto narrow = [](const sf_long* a, sf_long len) { std::vector<int32_t> v((size_t)std::max<sf_long>(len, 0)); for (sf_long k = 0; k < len; ++k) v[(size_t)k] = (int32_t)a[k]; return v; };
+        int rc = SF_OK;
+        if (!rc) rc = upload(&early.d_Lp, std::vector<int64_t>(Lp, Lp + n + 1), &early.bytes);
+        if (!rc) rc = upload(&early.d_Li, narrow(Li, nnz_in), &early.bytes);
+        if (!rc) rc = upload(&early.d_Super, narrow(Super, nsuper + 1), &early.bytes);
+        if (!rc) rc = upload(&early.d_SuperMap, narrow(SuperMap, n), &early.bytes);
+        if (!rc) rc = upload(&early.d_Lsip, std::vector<int64_t>(Lsip, Lsip + nsuper + 1), &early.bytes);
+        if (!rc) rc = upload(&early.d_Lsi, narrow(Lsi, isize_in), &early.bytes);
+        if (!rc) rc = upload(&early.d_Lsxp, std::vector<int64_t>(Lsxp, Lsxp + nsuper + 1), &early.bytes);
+        early.rc = rc;
     });
     struct JoinAlloc {
-        std::thread& t; double*& mem;
-        ~JoinAlloc() { if (t.joinable()) t.join(); if (mem) (void)hipFree(mem); }
-    } join_alloc{factor_alloc, factor_mem};
+        std::thread& t; double*& mem; EarlyUploads& e;
+        ~JoinAlloc() { if (t.joinable()) t.join(); if (mem) (void)hipFree(mem); e.release(); }
+    } join_alloc{factor_alloc, factor_mem, early};
     // ---------------- validate the structure the kernels index with ----------------
     for (sf_long s = 0; s < nsuper; ++s) {
         const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
@@ -1026,12 +1052,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
 
     const double pc_t3 = pc_now();
     // ---------------- upload ----------------
-    std::vector<int32_t> Li32(p->nnz), Super32(nsuper + 1), SuperMap32(n), Lsi32(p->isize);
-    for (sf_long k = 0; k < p->nnz; ++k) Li32[k] = (int32_t)Li[k];
+    std::vector<int32_t> Super32(nsuper + 1);
     for (sf_long k = 0; k <= nsuper; ++k) Super32[k] = (int32_t)Super[k];
-    for (sf_long k = 0; k < n; ++k) SuperMap32[k] = (int32_t)SuperMap[k];
-    for (sf_long k = 0; k < p->isize; ++k) Lsi32[k] = (int32_t)Lsi[k];
-    std::vector<int64_t> Lp64(Lp, Lp + n + 1), Lsip64(Lsip, Lsip + nsuper + 1), Lsxp64(Lsxp, Lsxp + nsuper + 1);
+    std::vector<int64_t> Lsip64(Lsip, Lsip + nsuper + 1), Lsxp64(Lsxp, Lsxp + nsuper + 1);
     p->h_Lsip = Lsip64; p->h_Lsxp = Lsxp64; p->h_Super = Super32;
     std::vector<int64_t> Up64;
     std::vector<int32_t> Ui32;
@@ -1082,13 +1105,19 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             for (hipEvent_t& e : p->dl_events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;    // the copy workers sleep on them
             if (!ok) { rc = SF_ERR_HIP; break; }
         }
-        if ((rc = up(&p->d_Lp, Lp64))) break;
-        if ((rc = up(&p->d_Li, Li32))) break;
-        if ((rc = up(&p->d_Super, Super32))) break;
-        if ((rc = up(&p->d_SuperMap, SuperMap32))) break;
-        if ((rc = up(&p->d_Lsip, Lsip64))) break;
-        if ((rc = up(&p->d_Lsi, Lsi32))) break;
-        if ((rc = up(&p->d_Lsxp, Lsxp64))) break;
+        // the structure arrays were uploaded by the helper thread (behind the factor's allocation); a schedule-only plan counts them
+        if (dry) {
+            p->bytes_device += (size_t)(n + 1) * 8 + (size_t)std::max<int64_t>(p->nnz, 1) * 4 + (size_t)(nsuper + 1) * 4 + (size_t)std::max<sf_long>(n, 1) * 4
+                               + (size_t)(nsuper + 1) * 8 + (size_t)std::max<int64_t>(p->isize, 1) * 4 + (size_t)(nsuper + 1) * 8;
+        } else {
+            factor_alloc.join();
+            if (factor_alloc_err != hipSuccess) { (void)hipGetLastError(); rc = SF_ERR_ALLOC; break; }
+            if (early.rc) { rc = early.rc; break; }
+            p->d_Lp = early.d_Lp; p->d_Li = early.d_Li; p->d_Super = early.d_Super; p->d_SuperMap = early.d_SuperMap;
+            p->d_Lsip = early.d_Lsip; p->d_Lsi = early.d_Lsi; p->d_Lsxp = early.d_Lsxp;
+            early.d_Lp = early.d_Lsip = early.d_Lsxp = nullptr; early.d_Li = early.d_Super = early.d_SuperMap = early.d_Lsi = nullptr;
+            p->bytes_device += early.bytes;
+        }
         if ((rc = up(&p->d_potrf, potrf))) break;
         if ((rc = up(&p->d_trsm, trsm))) break;
         if ((rc = up(&p->d_steps, steps))) break;
@@ -1206,7 +1235,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             if (L.kind == 2 || L.kind == 3 || L.kind == 4) { L.ticket = p->n_tickets; p->n_tickets += 8; }
         if (const char* env = sf_exp_env("SF_GEMM_DYNAMIC")) p->gemm_dynamic = atoi(env) != 0;
         const size_t xb = xb_factor, vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
-        factor_alloc.join();
+        if (factor_alloc.joinable()) factor_alloc.join();
         if (factor_alloc_err != hipSuccess) { (void)hipGetLastError(); rc = SF_ERR_ALLOC; break; }
         p->d_Lsx = factor_mem;
         factor_mem = nullptr;
