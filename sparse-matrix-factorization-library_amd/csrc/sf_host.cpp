@@ -44,6 +44,15 @@ T* dup_array(const std::vector<T, A>& v, size_t min_elems = 1) {
     return p;
 }
 
+// hand a RawVec's buffer to the caller as it is (malloc'ed: sf_symbolic.h); the vector keeps pointing at it until it is destroyed, its
+// deallocate then skips the stolen pointer.  Empty vectors get the one-element block the reference's callers may index.
+template <class T>
+T* steal_array(sf::RawVec<T>& v) {
+    if (v.empty()) return (T*)malloc(sizeof(T));
+    sf::raw_mark_stolen(v.data());
+    return v.data();
+}
+
 void free_and_null(void** p) {
     if (*p) free(*p);
     *p = nullptr;
@@ -132,7 +141,7 @@ const sf_long* sf_symbolic_long_array(const sf_symbolic* sym, const char* name, 
     const sf::Symbolic& S = sym->S;
     const std::string k(name);
     const std::vector<Long>* v = nullptr;
-    const sf::RawVec<Long>* w = (k == "Li") ? &S.Li : (k == "LTi") ? &S.LTi : (k == "Ui") ? &S.Ui : (k == "UTi") ? &S.UTi : nullptr;
+    const sf::RawVec<Long>* w = (k == "Li") ? &S.Li : (k == "LTi") ? &S.LTi : (k == "Ui") ? &S.Ui : (k == "UTi") ? &S.UTi : (k == "Lsi") ? &S.Lsi : nullptr;
     if (w) {
         if (len) *len = (sf_long)w->size();
         return (const sf_long*)w->data();
@@ -152,7 +161,6 @@ const sf_long* sf_symbolic_long_array(const sf_symbolic* sym, const char* name, 
     else if (k == "Sparent") v = &S.Sparent;
     else if (k == "Lsip") v = &S.Lsip;
     else if (k == "Lsxp") v = &S.Lsxp;
-    else if (k == "Lsi") v = &S.Lsi;
     else if (k == "LeafQueue") v = &S.LeafQueue;
     else if (k == "ST_Map") v = &S.ST_Map;
     else if (k == "ST_Pointer") v = &S.ST_Pointer;
@@ -350,8 +358,8 @@ int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_st
     SF_FREE(Lsip); SF_FREE(Lsxp); SF_FREE(Lsi); SF_FREE(Lsx);
     SF_FREE(ST_Map); SF_FREE(ST_Pointer); SF_FREE(ST_Index); SF_FREE(Aoffset); SF_FREE(Moffset);
 
-    mi->Lp = dup_array(S.Lp);   mi->Li = dup_array(S.Li);   mi->Lx = dup_array(S.Lx);
-    mi->LTp = dup_array(S.LTp); mi->LTi = dup_array(S.LTi); mi->LTx = dup_array(S.LTx);
+    mi->Lp = dup_array(S.Lp);   mi->Li = steal_array(S.Li);   mi->Lx = steal_array(S.Lx);
+    mi->LTp = dup_array(S.LTp); mi->LTi = steal_array(S.LTi); mi->LTx = steal_array(S.LTx);
     mi->Perm = dup_array(S.Perm);
     mi->Parent = dup_array(S.Parent);
     mi->Post = dup_array(S.Post);
@@ -369,7 +377,7 @@ int SparseFrame_analyze(struct common_info_struct* common, struct matrix_info_st
     mi->xsize = S.xsize;
     mi->Lsip = dup_array(S.Lsip);
     mi->Lsxp = dup_array(S.Lsxp);
-    mi->Lsi = dup_array(S.Lsi);
+    mi->Lsi = steal_array(S.Lsi);
     mi->Lsx = (sf_float*)malloc((S.xsize > 0 ? S.xsize : 1) * sizeof(sf_float));  // output, C:1647-1651
     mi->csize = S.csize;
     mi->nstage = S.nstage;

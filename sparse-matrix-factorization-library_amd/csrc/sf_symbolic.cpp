@@ -11,6 +11,7 @@
 //                    Lsi row structure, csize, stages, leaf queue, slot offsets)
 // The code is organised differently (separate passes over std::vector, no shared workspace
 // aliasing) but each pass is written to reproduce the reference's tie-breaking exactly.
+#include <mutex>
 #include "sf_symbolic.h"
 #include <atomic>
 #include <chrono>
@@ -23,6 +24,21 @@
 #include <cstring>
 
 namespace sf {
+
+// buffers of RawVec vectors that were handed to a caller who will free() them (sf_symbolic.h)
+static std::mutex g_stolen_mu;
+static std::vector<void*> g_stolen;
+void raw_mark_stolen(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_stolen_mu);
+    g_stolen.push_back(p);
+}
+bool raw_take_if_stolen(void* p) {
+    std::lock_guard<std::mutex> g(g_stolen_mu);
+    for (size_t k = 0; k < g_stolen.size(); ++k)
+        if (g_stolen[k] == p) { g_stolen[k] = g_stolen.back(); g_stolen.pop_back(); return true; }
+    return false;
+}
 
 namespace {
 
@@ -784,13 +800,22 @@ struct SpinBarrier {
     void wait() {
         const int g = gen.load(std::memory_order_acquire);
         if (cnt.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { cnt.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); }
-        else while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+        else {
+            // a BFS level of a grid is a few thousand vertices: the wait is usually shorter than a reschedule -- spin first, yield later
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == g) {
+                if (++spins < 512) __builtin_ia32_pause(); else std::this_thread::yield();
+            }
+        }
     }
 };
 
 // BFS of piece `id` from `root` by `team` threads.  order: the visited vertices, level by level (capacity `cap` >= piece size);
 // level[] filled; the marks of the visited vertices end as `final_mark`.  Returns the number of levels; *last_min = smallest vertex
 // of the last level.
+// Two barriers per BFS level (round 4; three before, and yielding ones: a 128^3 grid has ~380 levels of ~5,000 vertices, the sweep
+// was bound by its synchronisation -- 47 ms for 2M vertices on 16 threads): every thread keeps its own copy of the frontier bounds and
+// derives the next ones from the published per-thread counts (double-buffered), so nobody waits for a coordinator.
 Vx nd_bfs_team(NdCtx& c, Vx id, Vx root, int team, Vx cap, Vx final_mark, std::vector<Vx>& order, Vx* last_min) {
     team = std::max(1, team);
     order.assign((size_t)cap, 0);
@@ -798,17 +823,17 @@ Vx nd_bfs_team(NdCtx& c, Vx id, Vx root, int team, Vx cap, Vx final_mark, std::v
     order[0] = root;
     c.level[root] = 0;
     c.set_mk(root, vis);
-    Vx lo = 0, hi = 1, lev = 0;                       // frontier = order[lo, hi): written by thread 0 between barriers
     std::vector<std::vector<Vx>> local((size_t)team);
-    std::vector<Vx> sizes((size_t)team, 0);
+    std::vector<Vx> sizes[2] = {std::vector<Vx>((size_t)team, 0), std::vector<Vx>((size_t)team, 0)};
     SpinBarrier bar;
     bar.n = team;
-    bool done = false;
+    Vx out_lo = 0, out_hi = 1, out_lev = 0;             // written by thread 0 when it leaves the loop
     auto body = [&](int t) {
         std::vector<Vx>& mine = local[(size_t)t];
-        for (;;) {
+        Vx lo = 0, hi = 1, lev = 0;                     // frontier = order[lo, hi): every thread's own, identical copy
+        for (int par = 0;; par ^= 1) {
             const Vx F = hi - lo;
-            const Vx a = lo + F * t / team, b = lo + F * (t + 1) / team;
+            const Vx a = lo + (Vx)((int64_t)F * t / team), b = lo + (Vx)((int64_t)F * (t + 1) / team);
             mine.clear();
             for (Vx h = a; h < b; ++h) {
                 const Vx v = order[(size_t)h];
@@ -822,24 +847,21 @@ Vx nd_bfs_team(NdCtx& c, Vx id, Vx root, int team, Vx cap, Vx final_mark, std::v
                     }
                 }
             }
-            sizes[(size_t)t] = (Vx)mine.size();
-            bar.wait();
+            sizes[par][(size_t)t] = (Vx)mine.size();
+            bar.wait();                                 // all counts of this level are published
             Vx off = hi, total = 0;
-            for (int q = 0; q < team; ++q) { if (q < t) off += sizes[(size_t)q]; total += sizes[(size_t)q]; }
+            for (int q = 0; q < team; ++q) { if (q < t) off += sizes[par][(size_t)q]; total += sizes[par][(size_t)q]; }
             for (size_t k = 0; k < mine.size(); ++k) order[(size_t)off + k] = mine[k];
-            bar.wait();
-            if (t == 0) {
-                if (total == 0) done = true;
-                else { lo = hi; hi += total; ++lev; }
-            }
-            bar.wait();
-            if (done) return;
+            if (total == 0) { if (t == 0) { out_lo = lo; out_hi = hi; out_lev = lev; } return; }
+            lo = hi; hi += total; ++lev;
+            bar.wait();                                 // the next frontier is complete in order[]
         }
     };
     std::vector<std::thread> th;
     for (int t = 1; t < team; ++t) th.emplace_back(body, t);
     body(0);
     for (std::thread& x : th) x.join();
+    const Vx lo = out_lo, hi = out_hi, lev = out_lev;
     order.resize((size_t)hi);
     Vx mn = order[(size_t)lo];
     for (Vx h = lo; h < hi; ++h) mn = std::min(mn, order[(size_t)h]);
@@ -847,7 +869,7 @@ Vx nd_bfs_team(NdCtx& c, Vx id, Vx root, int team, Vx cap, Vx final_mark, std::v
     // marks: visited -> final_mark (split among the team)
     {
         const Vx N = hi;
-        auto fin = [&](int t) { for (Vx h = N * t / team; h < N * (t + 1) / team; ++h) c.set_mk(order[(size_t)h], final_mark); };
+        auto fin = [&](int t) { for (Vx h = (Vx)((int64_t)N * t / team); h < (Vx)((int64_t)N * (t + 1) / team); ++h) c.set_mk(order[(size_t)h], final_mark); };
         std::vector<std::thread> th2;
         for (int t = 1; t < team; ++t) th2.emplace_back(fin, t);
         fin(0);
@@ -862,8 +884,12 @@ void nd_component_big(NdCtx& c, std::vector<Vx>& comp, Vx pos, int team, Vx root
     const Vx id = c.mk(comp[0]);
     std::vector<Vx> order;
     Vx last_min = 0;
+    const bool tr_big = getenv("SF_TRACE_ND") != nullptr;
+    auto now_b = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tb0 = now_b();
     const Vx nlev = nd_bfs_team(c, id, root, team, (Vx)comp.size(), id, order, &last_min);
     { std::vector<Vx>().swap(order); }
+    const double tb1 = now_b();
     if (nlev < 3) {         // (nearly) complete graph: no useful separator
         for (Vx v : comp) { c.out[pos++] = v; c.set_mk(v, -1); }
         return;
@@ -889,6 +915,8 @@ void nd_component_big(NdCtx& c, std::vector<Vx>& comp, Vx pos, int team, Vx root
         else Sep.push_back(v);
     }
     for (Vx v : Sep) c.set_mk(v, -1);
+    if (tr_big) fprintf(stderr, "[sparseframe-hip]     big piece of %zu vertices, team %d: level structure %.1f ms, count + split %.1f ms\n",
+                        comp.size(), team, tb1 - tb0, now_b() - tb1);
     { std::vector<Vx>().swap(comp); }
     const Vx posA = pos, posB = pos + (Vx)A.size(), posS = posB + (Vx)B.size();
     const int team_a = std::max(1, team / 2), team_b = std::max(1, team - team_a);

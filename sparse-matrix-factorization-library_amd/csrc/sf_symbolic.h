@@ -2,7 +2,9 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
+#include <new>
 #include <utility>
 #include <vector>
 
@@ -11,13 +13,28 @@ namespace sf {
 using Long = int64_t;
 
 // std::vector whose resize() leaves new elements uninitialized: the index / value arrays of the triangles are tens to hundreds of
-// MB that are overwritten entry by entry right after; zero-filling them first is a single-threaded pass over fresh pages
+// MB that are overwritten entry by entry right after; zero-filling them first is a single-threaded pass over fresh pages.
+// Its storage comes from malloc, and a buffer can be STOLEN (raw_steal): the struct entry point SparseFrame_analyze hands the big
+// arrays to matrix_info as they are -- the reference's cleanup free()s them -- instead of copying 340 MB into fresh pages
+// (0.1 -> 0.03 s of the 128^3 analysis); the vector's destructor then finds the pointer in the stolen set and leaves it alone.
+void raw_mark_stolen(void* p);
+bool raw_take_if_stolen(void* p);       // true (and forgets p) if p was stolen: the caller must not free it
 template <class T>
-struct default_init_allocator : std::allocator<T> {
+struct default_init_allocator {
+    using value_type = T;
+    default_init_allocator() noexcept = default;
+    template <class U> default_init_allocator(const default_init_allocator<U>&) noexcept {}
     template <class U> struct rebind { using other = default_init_allocator<U>; };
-    using std::allocator<T>::allocator;
+    T* allocate(std::size_t n) {
+        void* p = std::malloc(n > 0 ? n * sizeof(T) : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, std::size_t) noexcept { if (p && !raw_take_if_stolen(p)) std::free(p); }
     template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
     template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const default_init_allocator<U>&) const noexcept { return true; }
+    template <class U> bool operator!=(const default_init_allocator<U>&) const noexcept { return false; }
 };
 template <class T> using RawVec = std::vector<T, default_init_allocator<T>>;
 
@@ -46,7 +63,8 @@ struct Symbolic {
 
     Long nfsuper = 0, nsuper = 0;
     std::vector<Long> Super, SuperMap, Sparent;
-    std::vector<Long> Lsip, Lsxp, Lsi;
+    std::vector<Long> Lsip, Lsxp;
+    RawVec<Long> Lsi;         // (stealable, see RawVec)
     Long isize = 0, xsize = 0, csize = 0;
 
     Long nstage = 0;
