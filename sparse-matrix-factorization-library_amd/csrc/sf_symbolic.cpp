@@ -11,6 +11,7 @@
 //                    Lsi row structure, csize, stages, leaf queue, slot offsets)
 // The code is organised differently (separate passes over std::vector, no shared workspace
 // aliasing) but each pass is written to reproduce the reference's tie-breaking exactly.
+#include <sched.h>
 #include <mutex>
 #include "sf_symbolic.h"
 #include <atomic>
@@ -24,6 +25,52 @@
 #include <cstring>
 
 namespace sf {
+
+// For the duration of an analysis call the calling thread -- and with it every helper thread it starts: new threads inherit the
+// mask -- stays on the CPUs of the NUMA node it is running on.  The passes walk n-entry arrays at random; on the two-socket hosts of
+// the MI355X boxes half of those accesses were remote: the built-in ordering of the 128^3 matrix takes 0.34 s with the threads
+// spread over both sockets and 0.26 s on one node (round 4, `taskset` experiment).  The caller's mask is restored on the way out;
+// SF_ANALYZE_PIN=0 turns this off.  Nothing happens when the mask already lies inside one node or the topology cannot be read.
+struct NodeAffinity {
+    cpu_set_t saved;
+    bool active = false;
+    NodeAffinity() {
+        if (const char* e = getenv("SF_ANALYZE_PIN")) if (atoi(e) == 0) return;
+        if (sched_getaffinity(0, sizeof saved, &saved) != 0) return;
+        const int cpu = sched_getcpu();
+        if (cpu < 0) return;
+        for (int node = 0; node < 64; ++node) {
+            char path[96];
+            snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+            FILE* f = fopen(path, "r");
+            if (!f) { if (node == 0) return; break; }
+            char buf[4096];
+            const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+            fclose(f);
+            if (!ok) continue;
+            cpu_set_t mine;
+            CPU_ZERO(&mine);
+            bool has = false;
+            for (char* q = buf; *q;) {                      // "0-63,128-191"
+                char* end;
+                const long a = strtol(q, &end, 10);
+                if (end == q) break;
+                long b = a;
+                if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); }
+                for (long k = a; k <= b && k < CPU_SETSIZE; ++k) { if (CPU_ISSET(k, &saved)) CPU_SET(k, &mine); if (k == cpu) has = true; }
+                q = (*end == ',') ? end + 1 : end;
+                if (*end != ',') break;
+            }
+            if (!has) continue;
+            const int cnt = CPU_COUNT(&mine);
+            if (cnt > 0 && cnt < CPU_COUNT(&saved) && sched_setaffinity(0, sizeof mine, &mine) == 0) active = true;
+            return;
+        }
+    }
+    ~NodeAffinity() { if (active) (void)sched_setaffinity(0, sizeof saved, &saved); }
+    NodeAffinity(const NodeAffinity&) = delete;
+    NodeAffinity& operator=(const NodeAffinity&) = delete;
+};
 
 // buffers of RawVec vectors that were handed to a caller who will free() them (sf_symbolic.h)
 static std::mutex g_stolen_mu;
@@ -166,6 +213,12 @@ void build_triangles(Long n, const Long* Cp, const Long* Ci, const double* Cx,
 // Long arrays at the interface).  I = int32_t for n < 2^31, Long otherwise.
 
 // Liu's elimination tree with path compression over the rows of L (columns of L^T).
+// In parallel over CLOSED RANGES (round 4).  Row j climbs from the columns of its entries, all inside [lo(j), j] with lo(j) its
+// leftmost column, and only writes Parent / Anc of indices in that interval.  A range [a, b] is closed when lo(j) >= a for every row
+// j in it: its rows never leave it.  The closed range ending at every row comes from one stack pass (ranges are nested or disjoint);
+// the maximal ones of at most n / (8 T) rows are independent tasks for the T analysis threads, the rows whose range is longer -- the
+// top separators of a dissection ordering, a few per cent of the matrix -- follow sequentially in ascending order.  Every row still
+// sees every lower row it shares an index with already processed, so the result is the sequential one (the tree is unique anyway).
 template <class I>
 void elimination_tree_t(const Symbolic& S, std::vector<Long>& Parent) {
     const Long n = S.n;
@@ -182,10 +235,64 @@ void elimination_tree_t(const Symbolic& S, std::vector<Long>& Parent) {
         }
     };
     const bool both = S.lu && !S.symmetric;     // LU: tree of the pattern of L + U^T (L:1358-1383)
-    for (Long j = 0; j < n; ++j) {
+    auto row = [&](Long j) {
         for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) climb(S.LTi[p], j);
         if (both)
             for (Long p = S.UTp[j]; p < S.UTp[j + 1]; ++p) climb(S.UTi[p], j);
+    };
+    const int T = analysis_threads();
+    if (T <= 1 || n < 20000) {
+        for (Long j = 0; j < n; ++j) row(j);
+    } else {
+        // closed range ending at every row: start[j]
+        std::vector<I> start(n);
+        {
+            std::vector<I> lo(n);
+            parallel_ranges(T, n, [&](int, Long j0, Long j1) {
+                for (Long j = j0; j < j1; ++j) {
+                    Long m = j;
+                    for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) m = std::min(m, S.LTi[p]);
+                    if (both)
+                        for (Long p = S.UTp[j]; p < S.UTp[j + 1]; ++p) m = std::min(m, S.UTi[p]);
+                    lo[j] = (I)m;
+                }
+            });
+            std::vector<std::pair<I, I>> st;        // (start, smallest lo) of the maximal closed ranges that tile [0, j)
+            st.reserve(1024);
+            for (Long j = 0; j < n; ++j) {
+                I a = (I)j, m = lo[j];
+                while (m < a) {                     // the row reaches left of its range: swallow the range before it
+                    a = st.back().first;
+                    m = std::min(m, st.back().second);
+                    st.pop_back();
+                }
+                st.emplace_back(a, m);
+                start[j] = a;
+            }
+        }
+        const Long smax = std::max<Long>(1024, n / (8 * (Long)T));
+        std::vector<std::pair<I, I>> tasks;         // maximal closed ranges of at most smax rows, right to left
+        std::vector<char> top(n, 0);
+        for (Long j = n - 1; j >= 0;) {
+            if ((Long)j - start[j] + 1 > smax) { top[j] = 1; --j; continue; }
+            tasks.emplace_back(start[j], (I)j);
+            j = (Long)start[j] - 1;
+        }
+        std::sort(tasks.begin(), tasks.end(), [](const std::pair<I, I>& x, const std::pair<I, I>& y) {
+            const Long sx = (Long)x.second - x.first, sy = (Long)y.second - y.first;
+            return sx != sy ? sx > sy : x.first < y.first;      // longest first
+        });
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1))
+                for (Long j = tasks[k].first; j <= tasks[k].second; ++j) row(j);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(worker);
+        worker();
+        for (std::thread& x : th) x.join();
+        for (Long j = 0; j < n; ++j)
+            if (top[j]) row(j);
     }
     Parent.resize(n);
     for (Long j = 0; j < n; ++j) Parent[j] = Par[j];
@@ -225,10 +332,30 @@ void postorder_t(const std::vector<Long>& Parent, const std::vector<Long>* Weigh
         std::vector<I> fill(cptr.begin(), cptr.end() - 1);
         for (I j : order) child[(size_t)fill[Parent[j]]++] = j;
     }
+    // No depth-first walk: with the subtree sizes (one ascending pass: parents follow their children in the elimination tree's
+    // numbering) every node's position is start + size - 1, where a node's children get consecutive start positions in visiting
+    // order (one descending pass over contiguous child lists).  Forests that are not numbered that way (a parent before a child: only
+    // a caller's hand-made Parent array could do that) take the stack walk.
+    bool topo = true;
+    for (Long j = 0; j < n && topo; ++j) topo = Parent[j] < 0 || Parent[j] > j;
+    Post.assign(n, -1);
+    if (topo) {
+        std::vector<I> size(n, 1), start(n, 0);
+        for (Long j = 0; j < n; ++j)
+            if (Parent[j] >= 0) size[Parent[j]] += size[j];
+        I run = 0;
+        for (Long r = 0; r < n; ++r)
+            if (Parent[r] < 0) { start[r] = run; run += size[r]; }          // roots in ascending index
+        for (Long j = n - 1; j >= 0; --j) {
+            I sp = start[j];
+            for (I q = cptr[j]; q < cptr[j + 1]; ++q) { const I ch = child[(size_t)q]; start[ch] = sp; sp += size[ch]; }
+        }
+        for (Long j = 0; j < n; ++j) Post[(size_t)start[j] + size[j] - 1] = j;
+        return;
+    }
     std::vector<I> next(cptr.begin(), cptr.end() - 1);      // next child of a node on the stack
     std::vector<I> Stack;
     Stack.reserve(1024);
-    Post.assign(n, -1);
     Long k = 0;
     for (Long r = 0; r < n; ++r) {
         if (Parent[r] >= 0) continue;           // roots in ascending index
@@ -318,6 +445,7 @@ int analyze_lu(Long n, const Long* Cp, const Long* Ci, const double* Cx,
 static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
                        const Long* perm, size_t devSlotSize, bool lu, bool symmetric, Symbolic& S) {
     if (n < 0 || !Cp || (n > 0 && !Ci)) return 1;
+    NodeAffinity on_one_node;
     S = Symbolic();
     S.n = n;
     S.devSlotSize = devSlotSize;
@@ -1050,6 +1178,7 @@ void nd_component(NdCtx& c, std::vector<Vx>& comp, Vx pos) {
 // Cp/Ci: any triangle (or both) of the symmetric pattern; the pattern is symmetrised.  perm[new] = old.
 int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm) {
     if (n < 0 || !Cp || (n > 0 && !Ci) || !perm || leaf < 1) return 1;
+    NodeAffinity on_one_node;
     const bool tr_nd = getenv("SF_TRACE") != nullptr;
     auto now_nd = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_nd0 = now_nd();
