@@ -875,6 +875,9 @@ namespace {
 // vertex ids, piece ids and BFS levels are 32-bit inside the dissection (n < 2^30, checked by graph_nd_perm): the sweeps are bound by
 // memory traffic over the adjacency, mark and level arrays, and halving them is a quarter of the ordering's time (round 4)
 using Vx = int32_t;
+// software prefetch in the sweeps: 1 = the team sweeps of the big pieces only (2M-vertex sweep 45 -> 25 ms); 2 = also the sequential sweeps of
+// the small pieces, which are mostly cache-resident -- no measurable difference in the whole ordering (0.25 - 0.31 s either way, box to box)
+static const int g_nd_prefetch = 1;
 struct NdCtx {
     const std::vector<Long>& Ap;
     const std::vector<Vx>& Ai;
@@ -897,6 +900,12 @@ void nd_bfs(NdCtx& c, Vx id, Vx root, std::vector<Vx>& order) {
     c.set_mk(root, -2 - id);        // visited: -2 - id (unique to the piece as well)
     for (size_t h = 0; h < order.size(); ++h) {
         const Vx v = order[h];
+        if (g_nd_prefetch >= 2 && h + 8 < order.size()) __builtin_prefetch(&c.Ap[order[h + 8]]);          // (see nd_bfs_team)
+        if (g_nd_prefetch >= 2 && h + 4 < order.size()) __builtin_prefetch(&c.Ai[c.Ap[order[h + 4]]]);
+        if (g_nd_prefetch >= 2 && h + 2 < order.size()) {
+            const Vx u = order[h + 2];
+            for (Long p = c.Ap[u]; p < c.Ap[u + 1]; ++p) __builtin_prefetch(&c.mark[c.Ai[p]]);
+        }
         for (Long p = c.Ap[v]; p < c.Ap[v + 1]; ++p) {
             const Vx w = c.Ai[p];
             if (c.mk(w) == id) {
@@ -965,6 +974,14 @@ Vx nd_bfs_team(NdCtx& c, Vx id, Vx root, int team, Vx cap, Vx final_mark, std::v
             mine.clear();
             for (Vx h = a; h < b; ++h) {
                 const Vx v = order[(size_t)h];
+                // the sweep is a chain of cache misses (offsets of v, its adjacency, the marks of its neighbours): ask for the
+                // offsets 16 vertices ahead, the adjacency 8 ahead and the neighbours' marks 4 ahead
+                if (g_nd_prefetch >= 1 && h + 16 < b) __builtin_prefetch(&c.Ap[order[(size_t)h + 16]]);
+                if (g_nd_prefetch >= 1 && h + 8 < b) __builtin_prefetch(&c.Ai[c.Ap[order[(size_t)h + 8]]]);
+                if (g_nd_prefetch >= 1 && h + 4 < b) {
+                    const Vx u = order[(size_t)h + 4];
+                    for (Long p = c.Ap[u]; p < c.Ap[u + 1]; ++p) __builtin_prefetch(&c.mark[c.Ai[p]]);
+                }
                 for (Long p = c.Ap[v]; p < c.Ap[v + 1]; ++p) {
                     const Vx w = c.Ai[p];
                     if (c.mk(w) != id) continue;
