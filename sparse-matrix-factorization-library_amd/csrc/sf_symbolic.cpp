@@ -212,6 +212,52 @@ void build_triangles(Long n, const Long* Cp, const Long* Ci, const double* Cx,
 // bound by cache misses, so their WORK arrays are 32-bit whenever n allows (round 4; the results are the same integers, the reference's
 // Long arrays at the interface).  I = int32_t for n < 2^31, Long otherwise.
 
+// The decomposition the parallel elimination tree and the parallel row-structure pass share: row j of L only concerns indices in
+// [lo(j), j], lo(j) = its leftmost column (from L^T, for the LU pattern also U^T).  tasks: the maximal CLOSED ranges (no row of the
+// range reaches left of it; one stack pass finds the closed range ending at every row, they are nested or disjoint) of at most
+// n / 8T rows, longest first; top[j] = 1 for the rows outside them (the top separators of a dissection ordering), to be handled
+// after all tasks in ascending order.  A row of a task never touches an index of another task or of a top row below it.
+void closed_range_tasks(const Symbolic& S, int T, std::vector<std::pair<Long, Long>>& tasks, std::vector<char>& top) {
+    const Long n = S.n;
+    const bool both = S.lu && !S.symmetric;
+    std::vector<Long> start(n), lo(n);
+    parallel_ranges(T, n, [&](int, Long j0, Long j1) {
+        for (Long j = j0; j < j1; ++j) {
+            Long m = j;
+            for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) m = std::min(m, S.LTi[p]);
+            if (both)
+                for (Long p = S.UTp[j]; p < S.UTp[j + 1]; ++p) m = std::min(m, S.UTi[p]);
+            lo[j] = m;
+        }
+    });
+    {
+        std::vector<std::pair<Long, Long>> st;      // (start, smallest lo) of the maximal closed ranges that tile [0, j)
+        st.reserve(1024);
+        for (Long j = 0; j < n; ++j) {
+            Long a = j, m = lo[j];
+            while (m < a) {                         // the row reaches left of its range: swallow the range before it
+                a = st.back().first;
+                m = std::min(m, st.back().second);
+                st.pop_back();
+            }
+            st.emplace_back(a, m);
+            start[j] = a;
+        }
+    }
+    const Long smax = std::max<Long>(1024, n / (8 * (Long)std::max(T, 1)));
+    tasks.clear();
+    top.assign(n, 0);
+    for (Long j = n - 1; j >= 0;) {
+        if (j - start[j] + 1 > smax) { top[j] = 1; --j; continue; }
+        tasks.emplace_back(start[j], j);
+        j = start[j] - 1;
+    }
+    std::sort(tasks.begin(), tasks.end(), [](const std::pair<Long, Long>& x, const std::pair<Long, Long>& y) {
+        const Long sx = x.second - x.first, sy = y.second - y.first;
+        return sx != sy ? sx > sy : x.first < y.first;
+    });
+}
+
 // Liu's elimination tree with path compression over the rows of L (columns of L^T).
 // In parallel over CLOSED RANGES (round 4).  Row j climbs from the columns of its entries, all inside [lo(j), j] with lo(j) its
 // leftmost column, and only writes Parent / Anc of indices in that interval.  A range [a, b] is closed when lo(j) >= a for every row
@@ -244,44 +290,9 @@ void elimination_tree_t(const Symbolic& S, std::vector<Long>& Parent) {
     if (T <= 1 || n < 20000) {
         for (Long j = 0; j < n; ++j) row(j);
     } else {
-        // closed range ending at every row: start[j]
-        std::vector<I> start(n);
-        {
-            std::vector<I> lo(n);
-            parallel_ranges(T, n, [&](int, Long j0, Long j1) {
-                for (Long j = j0; j < j1; ++j) {
-                    Long m = j;
-                    for (Long p = S.LTp[j]; p < S.LTp[j + 1]; ++p) m = std::min(m, S.LTi[p]);
-                    if (both)
-                        for (Long p = S.UTp[j]; p < S.UTp[j + 1]; ++p) m = std::min(m, S.UTi[p]);
-                    lo[j] = (I)m;
-                }
-            });
-            std::vector<std::pair<I, I>> st;        // (start, smallest lo) of the maximal closed ranges that tile [0, j)
-            st.reserve(1024);
-            for (Long j = 0; j < n; ++j) {
-                I a = (I)j, m = lo[j];
-                while (m < a) {                     // the row reaches left of its range: swallow the range before it
-                    a = st.back().first;
-                    m = std::min(m, st.back().second);
-                    st.pop_back();
-                }
-                st.emplace_back(a, m);
-                start[j] = a;
-            }
-        }
-        const Long smax = std::max<Long>(1024, n / (8 * (Long)T));
-        std::vector<std::pair<I, I>> tasks;         // maximal closed ranges of at most smax rows, right to left
-        std::vector<char> top(n, 0);
-        for (Long j = n - 1; j >= 0;) {
-            if ((Long)j - start[j] + 1 > smax) { top[j] = 1; --j; continue; }
-            tasks.emplace_back(start[j], (I)j);
-            j = (Long)start[j] - 1;
-        }
-        std::sort(tasks.begin(), tasks.end(), [](const std::pair<I, I>& x, const std::pair<I, I>& y) {
-            const Long sx = (Long)x.second - x.first, sy = (Long)y.second - y.first;
-            return sx != sy ? sx > sy : x.first < y.first;      // longest first
-        });
+        std::vector<std::pair<Long, Long>> tasks;
+        std::vector<char> top;
+        closed_range_tasks(S, T, tasks, top);
         std::atomic<size_t> next{0};
         auto worker = [&] {
             for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1))
@@ -590,7 +601,7 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     tm_[4] = now_();
     // ---- row structure: own columns, then every row j that reaches the supernode through
     //      the supernodal tree from the supernode of a nonzero (j,i), i<=j (C:1660-1692) ----
-    S.Lsi.assign(S.isize, -1);
+    S.Lsi.resize(S.isize);            // (uninitialised: every entry is written below -- the fill counts are checked against Lsip at the end)
     {
         std::vector<Long> fill(S.Lsip.begin(), S.Lsip.end() - 1), Marker(ns);
         for (Long s = 0; s < ns; ++s) {
@@ -598,19 +609,44 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
             for (Long k = S.Super[s]; k < S.Super[s + 1]; ++k) S.Lsi[fill[s]++] = k;
         }
         const bool both = lu && !symmetric;
-        for (Long j = 0; j < n; ++j) {
+        std::atomic<int> bad{0};
+        auto row = [&](Long j) {
             for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
                 const std::vector<Long>& Tp = pass ? S.UTp : S.LTp;
                 const RawVec<Long>& Ti = pass ? S.UTi : S.LTi;
                 for (Long p = Tp[j]; p < Tp[j + 1]; ++p) {
                     for (Long d = S.SuperMap[Ti[p]]; d >= 0 && Marker[d] <= j; d = S.Sparent[d]) {
-                        if (fill[d] >= S.Lsip[d + 1]) return 2;  // count mismatch: symbolic inconsistency
+                        if (fill[d] >= S.Lsip[d + 1]) { bad.store(1); return; }  // count mismatch: symbolic inconsistency
                         S.Lsi[fill[d]++] = j;
                         Marker[d] = j + 1;
                     }
                 }
             }
+        };
+        // Row j walks up the supernodal tree from the supernodes of its entries while their columns start at or before j: all
+        // inside [lo(j), j].  With the closed-range tasks of the elimination tree (closed_range_tasks, here on the FINAL numbering) a
+        // supernode only receives rows of its own task, in ascending order, and afterwards rows of the sequential top part: the same
+        // lists as the sequential pass (round 4: 65 -> 20 ms at 128^3).
+        const int T = analysis_threads();
+        if (T <= 1 || n < 20000) {
+            for (Long j = 0; j < n && !bad.load(std::memory_order_relaxed); ++j) row(j);
+        } else {
+            std::vector<std::pair<Long, Long>> tasks;
+            std::vector<char> top;
+            closed_range_tasks(S, T, tasks, top);
+            std::atomic<size_t> next{0};
+            auto worker = [&] {
+                for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1))
+                    for (Long j = tasks[k].first; j <= tasks[k].second; ++j) row(j);
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(worker);
+            worker();
+            for (std::thread& x : th) x.join();
+            for (Long j = 0; j < n; ++j)
+                if (top[j]) row(j);
         }
+        if (bad.load()) return 2;
         for (Long s = 0; s < ns; ++s)
             if (fill[s] != S.Lsip[s + 1]) return 2;
     }
