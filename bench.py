@@ -231,13 +231,11 @@ def self_launch(ngpu):
     """--gpus N > 1 with no launcher in the environment: start the N ranks as children (one process per GPU,
     torch.distributed.run on 127.0.0.1 with a free port) and leave with their exit code.  Runs before torch is imported:
     the parent never touches a GPU, rank 0's JSON line reaches stdout through the inherited descriptors."""
-    import socket
     import subprocess
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpu}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher opens its own rendezvous on a free port of 127.0.0.1 (no port picked here and closed again before
+    # the ranks bind it -- ADVICE r3: that was a race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={ngpu}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, SF_BENCH_SELF_LAUNCHED="1")
     sys.stderr.write(f"[bench.py] --gpus {ngpu} without a launcher: starting {ngpu} ranks: {' '.join(cmd)}\n")
     sys.stderr.flush()
