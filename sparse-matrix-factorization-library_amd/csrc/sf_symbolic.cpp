@@ -150,7 +150,10 @@ void build_stream(Long n, const Long* Cp, const Long* Ci, const double* Cx, cons
 // Stable bucket sort of the stream: entry e goes to bucket key(e) (-1: not in this part) carrying idx(e) and its value; inside a
 // bucket the entries keep the stream order (= the sequential fill of C:1036-1063).  Thread t owns the buckets [n t/T, n (t+1)/T): it
 // scans the whole key stream (sequential reads) and handles the keys of its range -- no atomics, no per-thread histograms, and its
-// scattered writes stay inside its own slice of the output.
+// scattered writes stay inside its own slice of the output.  (Round 4 tried the textbook alternative -- every thread routes the entries
+// of its CHUNK of the stream into T per-range lists, then each range is counted and placed from its lists: two passes over the data
+// instead of 2 T -- and it lost on the 2-socket host: triangles 50 - 73 -> 80 - 119 ms, renumber + triangles 76 - 90 -> 104 - 122 ms; the
+// lists are 200 MB of fresh pages written by 16 threads at once.)
 template <class K, class Ix>
 void bucket_stream(Long n, const EntryStream& st, int T, K&& key, Ix&& idx, std::vector<Long>& P, RawVec<Long>& I, RawVec<double>& X) {
     P.assign(n + 1, 0);
