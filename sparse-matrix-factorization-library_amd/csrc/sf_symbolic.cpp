@@ -386,6 +386,17 @@ void postorder(const std::vector<Long>& Parent, const std::vector<Long>* Weight,
 }
 
 // Column counts of L by the skeleton-leaf / disjoint-set method (C:1238-1352).
+// In parallel over SUBTREES (round 4).  The maximal subtrees of the elimination tree with at most n / 8T nodes are contiguous in the
+// postorder and independent up to the rows ABOVE them: a row inside a subtree only has entries in columns of the subtree, so its
+// skeleton is found with the subtree's own part of the arrays; for a row i above the subtree (a proper ancestor of its root r) the
+// FIRST column of the subtree with an entry in row i is always a leaf of row i's skeleton (everything before it in the postorder
+// lies before the subtree), the later ones are decided inside the subtree (previous neighbour and previous leaf are columns of the
+// subtree, their common ancestor lies inside it).  What cannot be decided inside is the common ancestor of that first leaf and the
+// row's previous leaf OUTSIDE the subtree, whose count is decremented: it is the lowest ancestor of the previous leaf that has not
+// been processed when the subtree starts -- a node above all subtrees -- and is found in the sequential stitch, which walks the
+// postorder, treats every subtree as one step (its recorded rows above: one find, one decrement, new previous leaf / neighbour) and
+// the nodes above the subtrees as the sequential algorithm does.  A find never enters a later subtree: the parent of a subtree's root
+// is such a top node, linked only when the stitch reaches it.  Same counts as the sequential pass, whatever the number of threads.
 template <class I>
 void column_counts_t(const Symbolic& S, const std::vector<Long>& Parent, const std::vector<Long>& Post,
                      std::vector<Long>& Count) {
@@ -397,27 +408,132 @@ void column_counts_t(const Symbolic& S, const std::vector<Long>& Parent, const s
     }
     for (Long j = 0; j < n; ++j) { Set[j] = (I)j; PrevLeaf[j] = (I)j; }
     const bool both = S.lu && !S.symmetric;     // LU: counts of the pattern of L + U^T (L:1601-1625)
-    for (Long k = 0; k < n; ++k) {
-        const I j = (I)Post[k];
-        PrevNbr[j] = (I)k;
+    auto find = [&](I x) {
+        I r = x;
+        while (r != Set[r]) r = Set[r];
+        for (I s = x; s != r;) { const I t = Set[s]; Set[s] = r; s = t; }
+        return r;
+    };
+    // the sequential step for column j = Post[k]: all of its entries (C:1300-1340)
+    auto column = [&](I j, I k) {
+        PrevNbr[j] = k;
         auto visit = [&](Long i0) {
             const I i = (I)i0;
             if (i <= j) return;
             if (First[j] > PrevNbr[i]) {
-                const I pl = PrevLeaf[i];
-                I r = pl;
-                while (r != Set[r]) r = Set[r];
-                for (I s = pl; s != r;) { const I t = Set[s]; Set[s] = r; s = t; }
+                const I r = find(PrevLeaf[i]);
                 Cnt[j]++;
                 Cnt[r]--;
                 PrevLeaf[i] = j;
             }
-            PrevNbr[i] = (I)k;
+            PrevNbr[i] = k;
         };
         for (Long p = S.Lp[j]; p < S.Lp[j + 1]; ++p) visit(S.Li[p]);
         if (both)
             for (Long p = S.Up[j]; p < S.Up[j + 1]; ++p) visit(S.Ui[p]);
         Set[j] = Par[j];
+    };
+    const int T = analysis_threads();
+    if (T <= 1 || n < 20000) {
+        for (Long k = 0; k < n; ++k) column((I)Post[k], (I)k);
+    } else {
+        std::vector<I> ipost(n), depth(n);
+        for (Long k = 0; k < n; ++k) ipost[Post[k]] = (I)k;
+        I maxdepth = 0;
+        for (Long j = n - 1; j >= 0; --j) {          // parents have larger indices than their children
+            depth[j] = Par[j] < 0 ? (I)0 : (I)(depth[Par[j]] + 1);
+            maxdepth = std::max(maxdepth, depth[j]);
+        }
+        const Long smax = std::max<Long>(1024, n / (8 * (Long)T));
+        auto size_of = [&](I j) { return (Long)ipost[j] - First[j] + 1; };
+        struct Task { I root, k0, k1; };
+        std::vector<Task> tasks;                   // in postorder
+        for (Long k = 0; k < n; ++k) {
+            const I j = (I)Post[k];
+            if (size_of(j) <= smax && (Par[j] < 0 || size_of(Par[j]) > smax)) tasks.push_back(Task{j, First[j], (I)k});
+        }
+        struct Above { I row, last_leaf, last_nbr; };
+        std::vector<std::vector<Above>> above(tasks.size());
+        std::vector<size_t> by_size(tasks.size());
+        for (size_t t = 0; t < tasks.size(); ++t) by_size[t] = t;
+        std::sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) {
+            const I sx = tasks[x].k1 - tasks[x].k0, sy = tasks[y].k1 - tasks[y].k0;
+            return sx != sy ? sx > sy : x < y;
+        });
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            // rows above the running subtree, by their distance from its root: stamp == task number + 1 marks a live entry
+            std::vector<I> stamp((size_t)maxdepth + 1, (I)0), lnbr((size_t)maxdepth + 1), lleaf((size_t)maxdepth + 1);
+            for (size_t q = next.fetch_add(1); q < by_size.size(); q = next.fetch_add(1)) {
+                const size_t t = by_size[q];
+                const Task tk = tasks[t];
+                const I dr = depth[tk.root], tag = (I)(t + 1);
+                std::vector<Above>& out = above[t];
+                for (I k = tk.k0; k <= tk.k1; ++k) {
+                    const I j = (I)Post[k];
+                    PrevNbr[j] = k;
+                    auto visit = [&](Long i0) {
+                        const I i = (I)i0;
+                        if (i <= j) return;
+                        if (ipost[i] <= tk.k1) {           // a row of the subtree: the sequential step
+                            if (First[j] > PrevNbr[i]) {
+                                const I r = find(PrevLeaf[i]);
+                                Cnt[j]++;
+                                Cnt[r]--;
+                                PrevLeaf[i] = j;
+                            }
+                            PrevNbr[i] = k;
+                            return;
+                        }
+                        const size_t d = (size_t)(dr - depth[i] - 1);       // i is a proper ancestor of the root
+                        if (stamp[d] != tag) {             // first column of the subtree in row i: a leaf, its partner is found by the stitch
+                            stamp[d] = tag;
+                            Cnt[j]++;
+                            lleaf[d] = j;
+                            out.push_back(Above{i, 0, 0});
+                        } else if (First[j] > lnbr[d]) {
+                            const I r = find(lleaf[d]);
+                            Cnt[j]++;
+                            Cnt[r]--;
+                            lleaf[d] = j;
+                        }
+                        lnbr[d] = k;
+                    };
+                    for (Long p = S.Lp[j]; p < S.Lp[j + 1]; ++p) visit(S.Li[p]);
+                    if (both)
+                        for (Long p = S.Up[j]; p < S.Up[j + 1]; ++p) visit(S.Ui[p]);
+                    Set[j] = Par[j];
+                }
+                for (Above& a : out) {
+                    const size_t d = (size_t)(dr - depth[a.row] - 1);
+                    a.last_leaf = lleaf[d];
+                    a.last_nbr = lnbr[d];
+                }
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(worker);
+            worker();
+            for (std::thread& x : th) x.join();
+        }
+        // the stitch: the postorder with every subtree as one step
+        size_t nt = 0;
+        for (Long k = 0; k < n;) {
+            if (nt < tasks.size() && tasks[nt].k0 == (I)k) {
+                for (const Above& a : above[nt]) {
+                    const I r = find(PrevLeaf[a.row]);
+                    Cnt[r]--;
+                    PrevLeaf[a.row] = a.last_leaf;
+                    PrevNbr[a.row] = a.last_nbr;
+                }
+                k = (Long)tasks[nt].k1 + 1;
+                ++nt;
+            } else {
+                column((I)Post[k], (I)k);
+                ++k;
+            }
+        }
     }
     Count.assign(n, 0);
     for (Long k = 0; k < n; ++k) {
@@ -512,7 +628,10 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
         S.Parent[k] = Parent[old] < 0 ? -1 : InvPost[Parent[old]];
         S.ColCount[k] = Count[old];
     }
-    build_triangles(n, Cp, Ci, Cx, S.Perm, S);
+    // the triangles of the final numbering are needed by the row-structure pass only: they are rebuilt (by their own threads)
+    // while this thread finds the supernodes, which read Parent and ColCount and nothing else (round 4)
+    std::thread tri([&] { build_triangles(n, Cp, Ci, Cx, S.Perm, S); });
+    struct JoinTri { std::thread& t; ~JoinTri() { if (t.joinable()) t.join(); } } join_tri{tri};
     tm_[3] = now_();
 
     const std::vector<Long>& Par = S.Parent;
@@ -601,6 +720,7 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
     S.isize = S.Lsip[ns];
     S.xsize = S.Lsxp[ns];
 
+    tri.join();
     tm_[4] = now_();
     // ---- row structure: own columns, then every row j that reaches the supernode through
     //      the supernodal tree from the supernode of a nonzero (j,i), i<=j (C:1660-1692) ----
@@ -764,8 +884,8 @@ static int analyze_any(Long n, const Long* Cp, const Long* Ci, const double* Cx,
         for (Long k = S.ST_Pointer[st]; k < S.ST_Pointer[st + 1]; ++k) S.Moffset[S.ST_Index[k]] += (Long)asz;
     }
     if (tr_)
-        fprintf(stderr, "[sparseframe-hip] analyze: triangles %.1f ms, etree + postorder + column counts %.1f ms, renumber + triangles %.1f ms, "
-                        "supernodes %.1f ms, row structure %.1f ms, csize + stages + offsets %.1f ms\n", tm_[1] - tm_[0], tm_[2] - tm_[1],
+        fprintf(stderr, "[sparseframe-hip] analyze: triangles %.1f ms, etree + postorder + column counts %.1f ms, renumber %.1f ms, "
+                        "supernodes beside the triangles' rebuild %.1f ms, row structure %.1f ms, csize + stages + offsets %.1f ms\n", tm_[1] - tm_[0], tm_[2] - tm_[1],
                 tm_[3] - tm_[2], tm_[4] - tm_[3], tm_[5] - tm_[4], now_() - tm_[5]);
     return 0;
 }

@@ -110,6 +110,27 @@ n, Cp, Ci, Cx = sf.gen.unsymmetric_stencil(g, g, g, seed=4)
 S = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(g, g, g), 1 << 30, "lu", False)
 for k in ("Lp", "Li", "LTi", "Up", "Ui", "UTp", "UTi", "Super", "Lsi", "Lx", "Ux", "UTx"):
     out["lu." + k] = hashlib.sha256(getattr(S, k).tobytes()).hexdigest()
+# round 4: the elimination tree and the row structures run in parallel over closed ranges, the column counts over subtrees with a
+# sequential stitch -- on orderings with long chains (natural order, a band), wide top parts (a random permutation), an arrow head,
+# a forest of single nodes, and a relaxed small-slot analysis
+import numpy as np
+def more(name, *a):
+    S = sf.analyze(*a)
+    for k in ("Parent", "ColCount", "Perm", "Post", "Parent0", "ColCount0", "Super", "Lsip", "Lsxp", "Lsi"):
+        out[name + "." + k] = hashlib.sha256(np.asarray(getattr(S, k)).tobytes()).hexdigest()
+g = 30
+n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
+more("natural", n, Cp, Ci, Cx, None, 8 << 30)
+more("random", n, Cp, Ci, Cx, np.random.default_rng(1).permutation(n), 8 << 30)
+n, Cp, Ci, Cx = sf.gen.unsymmetric_stencil(g, g, g, seed=3)
+more("lu_natural", n, Cp, Ci, Cx, None, 8 << 30, "lu", False)
+n, Cp, Ci, Cx = sf.gen.stencil_spd_lower(200, 200)
+more("stencil2d_smallslot", n, Cp, Ci, Cx, sf.grid_nd_perm(200, 200, 1, 3, 2), 200000)
+n, Cp, Ci, Cx = sf.gen.arrow_spd_lower(30000, 3)
+more("arrow", n, Cp, Ci, Cx, None, 8 << 30)
+n, Cp, Ci, Cx = sf.gen.random_spd_lower(40000, 2, seed=2, bandwidth=30)
+more("band", n, Cp, Ci, Cx, None, 8 << 30)
+more("diag", 50000, np.arange(50001), np.arange(50000), np.ones(50000), None, 8 << 30)
 g = 46
 n, Cp, Ci, Cx = sf.gen.laplacian_lower(g, g, g)
 out["graph_nd_perm"] = hashlib.sha256(sf.graph_nd_perm(n, Cp, Ci).tobytes()).hexdigest()
@@ -136,3 +157,29 @@ print(json.dumps(out))
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert res[0] == res[1] == res[2]
+
+
+def test_parallel_graph_passes_equal_the_oracle(oracle):
+    """above 20,000 rows the elimination tree, the row structures (closed ranges) and the column counts (subtrees + stitch) run on
+    several threads (round 4): every integer array against the pure-Python restatement of the reference, Cholesky and LU, dissection
+    and natural order, in a process that runs the analysis with 8 threads"""
+    import subprocess, sys
+    code = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+sf = importlib.import_module("sparse-matrix-factorization-library_amd")
+import oracle
+for lu in (False, True):
+    g = 28
+    n, Cp, Ci, Cx = (sf.gen.unsymmetric_stencil(g, g, g, seed=3) if lu else sf.gen.laplacian_lower(g, g, g))
+    for perm in (sf.grid_nd_perm(g, g, g, 3, 1), None):
+        O = oracle.symbolic.analyze(n, Cp, Ci, Cx, perm, 1 << 30, lu=lu, symmetric=not lu)
+        S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu" if lu else "cholesky", not lu)
+        for k in ("Parent", "ColCount", "Perm", "Post", "Super", "SuperMap", "Sparent", "Lsip", "Lsxp", "Lsi", "LeafQueue"):
+            assert np.array_equal(np.asarray(getattr(S, k)), np.asarray(O[k])), (lu, perm is None, k)
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SF_ANALYZE_THREADS="8"), capture_output=True, text=True,
+                       cwd=os.path.dirname(HERE), timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
