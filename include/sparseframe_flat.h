@@ -152,6 +152,28 @@ int sf_chol_plan_factorize_phase(sf_chol_plan *plan, int phase /* 0, 1, or -1 = 
 /* device pointer and length (doubles) of the contiguous region holding every top panel */
 int sf_chol_plan_top_region(sf_chol_plan *plan, void **device_ptr, sf_long *count);
 
+/* ---- a factor LARGER than the device's memory (the reference streams slot-sized "stages" through the device and keeps the factor
+ * on the host, C:1721-1846, C:2421-2467; here: whole subtrees).  sf_ooc_partition cuts the supernodal tree for a budget of
+ * `budget_entries` resident panel entries (doubles; LU stores two per entry): group[s] = streamed group of supernode s (whole
+ * subtrees, consecutive in the postorder) or -1 = top.  The plan keeps the top panels resident and streams the groups through two
+ * alternating buffers: group g is factorized while group g - 1 is copied to the host (device need = top + 2 x largest group;
+ * *need_entries).  SF_OK: fits (ngroups == 1: in core); SF_ERR_ALLOC: no cut fits, group[] holds the cheapest one.
+ * An out-of-core plan runs through sf_chol_plan_factorize_to_host only (the factor exists on the host, never as a whole on the
+ * device): it refuses solve / validate / get_factor (SF_ERR_ARG).  SparseFrame_factorize picks this path by itself when the
+ * in-core plan does not fit (SF_DEVICE_BUDGET_MB lowers the budget for tests). ---- */
+int sf_ooc_partition(sf_long nsuper, const sf_long *Super, const sf_long *SuperMap, const sf_long *Lsip, const sf_long *Lsi,
+                     sf_long budget_entries, int32_t *group, int *ngroups, sf_long *group_entries, sf_long *top_entries,
+                     sf_long *need_entries);
+int sf_chol_plan_create_ooc(sf_chol_plan **plan, int device, sf_long n, sf_long nsuper,
+                            const sf_long *Super, const sf_long *SuperMap,
+                            const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                            const sf_long *Lp, const sf_long *Li, const int32_t *group, int ngroups);
+/* the same plan without a device (launch list, storage map, byte counts only; see sf_chol_plan_schedule_mapped) */
+int sf_chol_plan_schedule_ooc(sf_chol_plan **plan, sf_long n, sf_long nsuper,
+                              const sf_long *Super, const sf_long *SuperMap,
+                              const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                              const sf_long *Lp, const sf_long *Li, const int32_t *group, int ngroups);
+
 /* ---- distributed top: the top supernodes' large GEMMs are SPLIT over the ranks instead of
  * replicated.  Every top panel is summed over the ranks exactly once, one 512-column block at a time, right before
  * the block's sequential 64-column POTRF/TRSM chain (the only replicated work); everything that updates a block
@@ -290,6 +312,12 @@ int sf_lu_plan_schedule_mapped(sf_lu_plan **plan, sf_long n, sf_long nsuper,
                                const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                                const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
                                const int32_t *owner, int rank, int nranks);   /* schedule-only, see sf_chol_plan_schedule_mapped */
+/* out of core: as sf_chol_plan_create_ooc (budget: two device doubles per panel entry) */
+int sf_lu_plan_create_ooc(sf_lu_plan **plan, int device, sf_long n, sf_long nsuper,
+                          const sf_long *Super, const sf_long *SuperMap,
+                          const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
+                          const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
+                          const int32_t *group, int ngroups);
 int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *Ux /* NULL if U aliases L */);
 /* Pivoting (BASELINE config 5 asks for it, the reference has none: magma_dgetrf_nopiv L:2653, devIpiv = NULL
  * L:3344, static pre-pivot L:589-673 disabled).  The symbolic structure is static, so rows can only be exchanged where that

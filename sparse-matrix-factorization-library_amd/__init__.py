@@ -10,7 +10,7 @@ the numeric entry points raise.
 """
 from ._lib import lib, LIB_PATH, SparseFrameError  # noqa: F401
 from .api import (  # noqa: F401
-    Symbolic, CholPlan, LUPlan, Schedule, Comm, MatrixInfo, LUMatrixInfo, CommonInfo, analyze, grid_nd_perm, graph_nd_perm, device_count, subtree_partition, phases_for_rank, top_groups, validate_solution,
+    Symbolic, CholPlan, LUPlan, Schedule, Comm, MatrixInfo, LUMatrixInfo, CommonInfo, analyze, grid_nd_perm, graph_nd_perm, device_count, subtree_partition, ooc_partition, phases_for_rank, top_groups, validate_solution,
     REFERENCE_SLOT_1GPU, REFERENCE_SLOT_8GPU,
 )
 from . import gen  # noqa: F401

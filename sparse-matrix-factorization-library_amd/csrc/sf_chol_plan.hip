@@ -115,7 +115,14 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                        const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                        const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
                        const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1,
-                       const uint32_t* top_mask = nullptr, const double* root_cum = nullptr, bool dry = false) {
+                       const uint32_t* top_mask = nullptr, const double* root_cum = nullptr, bool dry = false,
+                       const int32_t* ooc_group = nullptr, int ooc_ngroups = 0) {
+    // ooc_group (one device, nranks == 1, no phase array): OUT-OF-CORE plan -- the factor does not stay on the device.  ooc_group[s] in
+    // [0, ooc_ngroups) = the streamed group of supernode s (sf::ooc_partition: whole subtrees, consecutive in the postorder), -1 = top.
+    // The top panels are resident; the groups' panels alias TWO buffers of the largest group's size (group g lives in buffer g & 1)
+    // and are factorized group by group, group g while group g - 1 is copied to the host; a group's buffer is zeroed and assembled
+    // again (launch kind 7) once the copy of group g - 2 has left the device.  Such a plan only runs through the overlapped download
+    // (sf_chol_plan_factorize_to_host); it cannot solve or hand out its factor (partial).
     // dry: build the SCHEDULE only (launch list, segments, solve reduces, storage map, byte counts) -- no device is touched, nothing is
     // allocated or uploaded, and the resulting plan can only be inspected (sf_chol_plan_launch_info & co.) and destroyed.  It is the
     // same code path as a real plan up to the uploads, which is the point: what a rank WOULD do at a size or rank count this box cannot
@@ -129,6 +136,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     if (!out) return SF_ERR_ARG;
     *out = nullptr;
     if (nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks || (nranks > 1 && !phase_in)) return SF_ERR_ARG;
+    const bool ooc = ooc_group != nullptr && ooc_ngroups > 1;
+    if (ooc && (nranks != 1 || phase_in || ooc_ngroups > 32767)) return SF_ERR_ARG;
     if (n < 0 || nsuper < 0 || !Super || !Lsip || !Lsxp || !Lp || (n > 0 && (!SuperMap || !Lsi || !Li))) return SF_ERR_ARG;
     if (n >= (sf_long)0x7fffffff) return SF_ERR_ARG;   // device row indices are 32-bit
     if (!dry) {
@@ -159,6 +168,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // (phase 1) panels, contiguous, so that the multi-GPU merge is ONE all-reduce over [top_off, top_off+top_size).
     // With no phase array every supernode is phase 0 and the layout is the reference's Lsxp (Cholesky).
     p->phase.assign(nsuper, 0);
+    if (ooc) {
+        for (sf_long s = 0; s < nsuper; ++s) {
+            if (ooc_group[s] < -1 || ooc_group[s] >= ooc_ngroups) { delete p; return SF_ERR_ARG; }
+            p->phase[s] = ooc_group[s] < 0 ? 1 : 0;
+        }
+        p->ooc_groups = ooc_ngroups;
+    }
     if (phase_in)
         for (sf_long s = 0; s < nsuper; ++s) {
             if (phase_in[s] < -1 || phase_in[s] > 1) { delete p; return SF_ERR_ARG; }
@@ -183,7 +199,25 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     }
     auto group_idx = [&](uint32_t m) { return __builtin_popcount(m & ((1u << rank) - 1u)); };
     std::vector<int64_t> XP(nsuper + 1, -1);
-    {
+    if (ooc) {
+        // two buffers of the largest group's size, then the top; group g's panels from the start of buffer g & 1
+        std::vector<int64_t> gsz((size_t)ooc_ngroups, 0);
+        for (sf_long s = 0; s < nsuper; ++s)
+            if (ooc_group[s] >= 0) gsz[(size_t)ooc_group[s]] += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
+        p->ooc_buf = *std::max_element(gsz.begin(), gsz.end());
+        std::vector<int64_t> run((size_t)ooc_ngroups);
+        for (int g = 0; g < ooc_ngroups; ++g) run[(size_t)g] = (g & 1) * p->ooc_buf;
+        int64_t top = 2 * p->ooc_buf;
+        p->top_off = top;
+        for (sf_long s = 0; s < nsuper; ++s) {
+            int64_t& r = ooc_group[s] >= 0 ? run[(size_t)ooc_group[s]] : top;
+            XP[s] = r;
+            r += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
+        }
+        p->top_size = top - p->top_off;
+        p->xC = top;
+        XP[nsuper] = top;
+    } else {
         int64_t run = 0;
         for (int ph = 0; ph < 2; ++ph) {
             if (ph == 1) p->top_off = run;
@@ -198,6 +232,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     for (sf_long s = 0; s < nsuper; ++s)
         if (p->phase[s] != 0) p->partial = true;
     if (load_top != 1) p->partial = true;
+    if (ooc) p->partial = true;         // (also without a top -- a forest: the panels sit at aliased offsets, and there is no resident factor)
     const int64_t ushift = p->xC;     // PU(s) = PL(s) + ushift
 
     const bool trace_pc = getenv("SF_TRACE") != nullptr;
@@ -357,9 +392,21 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // The sweep: one set of independent supernodes at a time -- phase 0: a level of the owned subtrees; phase 1: the top
     // supernodes of one level that share one group of ranks (ascending mask: every rank meets the sets it shares with
     // another rank in the same order, so the groups' collectives cannot wait for each other in a circle).
-    struct LevelSet { int ph; std::vector<sf_long> sn; uint32_t mask; int share_idx, share_cnt; double lo = 0.0, hi = 1.0; };
+    struct LevelSet { int ph; std::vector<sf_long> sn; uint32_t mask; int share_idx, share_cnt; double lo = 0.0, hi = 1.0; int group = -1; };
     std::vector<LevelSet> sets;
-    for (int ph = 0; ph < 2; ++ph) {
+    if (ooc) {      // out of core: the groups one after the other, each with its own level sets (then the top, below)
+        std::vector<std::vector<std::vector<sf_long>>> by_gl((size_t)ooc_ngroups);
+        for (sf_long s = 0; s < nsuper; ++s)
+            if (ooc_group[s] >= 0) {
+                auto& bl = by_gl[(size_t)ooc_group[s]];
+                if ((int)bl.size() <= level[s]) bl.resize((size_t)level[s] + 1);
+                bl[(size_t)level[s]].push_back(s);
+            }
+        for (int g = 0; g < ooc_ngroups; ++g)
+            for (auto& v : by_gl[(size_t)g])
+                if (!v.empty()) { sets.push_back(LevelSet{0, std::move(v), 0, 0, 1}); sets.back().group = g; }
+    }
+    for (int ph = ooc ? 1 : 0; ph < 2; ++ph) {
         std::vector<std::vector<sf_long>> by_level(nlevels);
         for (sf_long s = 0; s < nsuper; ++s)
             if (p->phase[s] == ph) by_level[level[s]].push_back(s);
@@ -383,9 +430,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     }
     p->launch_split = 0;
     bool split_set = false;
+    int ooc_open = -1;          // out of core: the group whose (zero + assemble) launch has been issued last
     for (const LevelSet& LS : sets) {
     const int ph = LS.ph;
     if (ph == 1 && !split_set) { p->launch_split = p->launches.size(); split_set = true; }
+    // out of core: every group starts by zeroing and assembling its buffer (kind 7, first = the group); groups without supernodes
+    // still get theirs, so that the buffers' turn-taking is the same whatever the tree looks like
+    while (ooc && LS.group > ooc_open) p->launches.push_back(Launch{7, (int64_t)++ooc_open, 0});
     {
         const std::vector<sf_long>& Sl = LS.sn;
         const bool shared = ph == 1 && nranks > 1;          // additive updates split over the group, block columns reduced
@@ -913,6 +964,8 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         std::vector<uint32_t> run_mask;
         int last_phase = -2;
         uint32_t last_mask = 0;
+        int32_t last_group = -2;        // out of core: a piece never spans two groups (each group's copy is counted on its own)
+        auto grp = [&](sf_long s) { return ooc ? ooc_group[s] : (int32_t)-1; };
         // LU: the reference keeps one packed panel per supernode, column j = [ L11 \ U11 (nscol) | L21 | U12^T ] (L:2514-2517), the
         // device an L panel and a U^T panel.  DIRECT form (default): the pieces are whole columns; the compute stream writes U11 into
         // the (unused) upper triangle of the L panel's diagonal block before a piece's event (k_lu_fill_u11), the L and U^T runs
@@ -937,7 +990,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                     DlPiece pc{XP[s], Lsxp[s], nscol * hld, ready, 0};
                     pc.s0 = (int32_t)s; pc.s1 = (int32_t)s + 1; pc.dev_count = cntL;
                     const bool can_merge = !runs.empty() && runs.back().s0 >= 0 && runs.back().ld == 0 && runs.back().s1 == (int32_t)s &&
-                                           last_phase == p->phase[s] && last_mask == gmask[s] &&
+                                           last_phase == p->phase[s] && last_mask == gmask[s] && last_group == grp(s) &&
                                            runs.back().dev_off + runs.back().dev_count == pc.dev_off &&
                                            runs.back().host_off + runs.back().count == pc.host_off &&
                                            2 * (runs.back().dev_count + cntL) <= DL_SLOT;
@@ -963,6 +1016,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 }
                 last_phase = p->phase[s];
                 last_mask = gmask[s];
+                last_group = grp(s);
                 continue;
             }
             for (int64_t jo = 0; jo * sf::OUTER_NB < nscol; ++jo) {
@@ -973,6 +1027,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 const bool two_d = !lu && J > 0 && dl_2d;
                 if (two_d) { pc.skip = J; pc.ld = nsrow; pc.ncols = w; pc.count = w * (nsrow - J); }
                 const bool can_merge = !two_d && !runs.empty() && runs.back().ld == 0 && last_phase == p->phase[s] && last_mask == gmask[s] &&
+                                       last_group == grp(s) &&
                                        runs.back().host_off + runs.back().count == pc.host_off &&
                                        (lu || runs.back().dev_off + runs.back().count == pc.dev_off) &&
                                        runs.back().count + pc.count <= DL_SLOT;
@@ -986,6 +1041,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 }
                 last_phase = p->phase[s];
                 last_mask = gmask[s];
+                last_group = grp(s);
             }
         }
         std::vector<std::pair<uint32_t, int64_t>> seen_by_mask;     // pieces of a group's panels are dealt out inside the group
@@ -1029,6 +1085,16 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 p->dl_pieces.push_back(DlPiece{r.dev_off + o, r.host_off + o, std::min(DL_SLOT, r.count - o), r.ready, 0});
         }
         std::stable_sort(p->dl_pieces.begin(), p->dl_pieces.end(), [](const DlPiece& a, const DlPiece& b) { return a.ready < b.ready; });
+        if (ooc) {
+            // the group of every piece (from the supernode its first host entry belongs to) and the number of pieces per group: what
+            // the launch that re-uses a buffer waits for
+            p->dl_group_pieces.assign((size_t)ooc_ngroups, 0);
+            for (DlPiece& pc : p->dl_pieces) {
+                const sf_long s = (sf_long)(std::upper_bound(Lsxp, Lsxp + nsuper + 1, (sf_long)pc.host_off) - Lsxp) - 1;
+                pc.group = (s >= 0 && s < nsuper) ? ooc_group[s] : -1;
+                if (pc.group >= 0) ++p->dl_group_pieces[(size_t)pc.group];
+            }
+        }
         for (DlPiece& pc : p->dl_pieces) {
             if (p->dl_ev_ready.empty() || p->dl_ev_ready.back() != pc.ready) p->dl_ev_ready.push_back(pc.ready);
             pc.ev = (int)p->dl_ev_ready.size() - 1;
@@ -1202,7 +1268,13 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             if (!dalloc((void**)&p->d_status, sizeof(double))) { rc = SF_ERR_ALLOC; break; }
             p->bytes_device += sizeof(double);
         }
-        if (p->partial) {
+        if (ooc) {
+            // one assembly mask per group, then the top's: d_loadmask + g * nsuper (g = ooc_ngroups: the top)
+            std::vector<int8_t> mask((size_t)(ooc_ngroups + 1) * (size_t)std::max<sf_long>(nsuper, 1), 0);
+            for (sf_long s = 0; s < nsuper; ++s)
+                mask[(size_t)(ooc_group[s] >= 0 ? ooc_group[s] : ooc_ngroups) * (size_t)nsuper + (size_t)s] = 1;
+            if ((rc = up(&p->d_loadmask, mask))) break;
+        } else if (p->partial) {
             std::vector<int8_t> mask(std::max<sf_long>(nsuper, 1), 0);
             // the matrix entries of a shared top panel enter the sum once: on the first rank of its group (load_top == 2),
             // or on the rank the caller names (load_top 0 / 1: the older interface, one group of all ranks)
@@ -1263,6 +1335,35 @@ int sf_chol_plan_create_sharded(sf_chol_plan** out, int device, sf_long n, sf_lo
                                 const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
                                 const sf_long* Lp, const sf_long* Li, const int32_t* phase, int load_top) {
     return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, phase, load_top);
+}
+
+// Out-of-core plans (plan_create, ooc_group): group[] from sf_ooc_partition; ngroups <= 1 gives the ordinary in-core plan.
+int sf_chol_plan_create_ooc(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
+                            const sf_long* Super, const sf_long* SuperMap,
+                            const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                            const sf_long* Lp, const sf_long* Li, const int32_t* group, int ngroups) {
+    if (ngroups > 1 && !group) return SF_ERR_ARG;
+    return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, nullptr, 1, 0, 1,
+                       nullptr, nullptr, false, group, ngroups);
+}
+
+// schedule-only out-of-core plan (no device; see sf_chol_plan_schedule_mapped): what the launch list and the storage would be
+int sf_chol_plan_schedule_ooc(sf_chol_plan** out, sf_long n, sf_long nsuper,
+                              const sf_long* Super, const sf_long* SuperMap,
+                              const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                              const sf_long* Lp, const sf_long* Li, const int32_t* group, int ngroups) {
+    if (ngroups > 1 && !group) return SF_ERR_ARG;
+    return plan_create(out, 0, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, nullptr, 1, 0, 1,
+                       nullptr, nullptr, true, group, ngroups);
+}
+
+int sf_lu_plan_create_ooc(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
+                          const sf_long* Super, const sf_long* SuperMap,
+                          const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
+                          const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui, const int32_t* group, int ngroups) {
+    if (ngroups > 1 && !group) return SF_ERR_ARG;
+    return plan_create(out, device, true, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, nullptr, 1, 0, 1,
+                       nullptr, nullptr, false, group, ngroups);
 }
 
 int sf_chol_plan_create_distributed(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
@@ -1495,6 +1596,7 @@ static inline void launch_window(const Launch& L, int64_t total, int64_t* lo, in
 static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool last, int sync) {
     if (!p->values_set) return SF_ERR_ARG;
     if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
+    if (p->ooc_groups > 1 && !p->dl_active) return SF_ERR_ARG;      // an out-of-core plan only exists together with its copy-back
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = p->stream;
     struct EventList {      // profiling events; destroyed on every exit path
@@ -1522,25 +1624,30 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         pc.nperturb = (int*)(p->d_piv + 2 * std::max<int64_t>(p->n, 1));
         if (first) HIP_TRY(hipMemsetAsync(pc.nperturb, 0, sizeof(int), st));
     }
-    if (first) {
-        HIP_TRY(hipMemsetAsync(p->d_info, 0, (1 + p->n_tickets) * sizeof(int), st));
-        if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
+    // the matrix entries of the panels `mask` selects (nullptr: all) into the zeroed panels
+    auto assemble = [&](const int8_t* mask, hipStream_t s_) {
         const int64_t* xp = (p->lu || p->partial) ? p->d_Xp : p->d_Lsxp;
         if (!p->lu) {
             sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                                   p->d_Lsi, xp, p->d_Lsx, 0, p->d_loadmask, st);
+                                   p->d_Lsi, xp, p->d_Lsx, 0, mask, s_);
         } else {
             // L panel: strictly lower entries of the columns of L; U^T panel: row j of U (diagonal included) goes to
             // column j of PU at the positions of its column indices (reference loadA, L:2490-2533)
             sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                                   p->d_Lsi, xp, p->d_Lsx, 1, p->d_loadmask, st);
+                                   p->d_Lsi, xp, p->d_Lsx, 1, mask, s_);
             if (p->u_alias)
                 sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                                       p->d_Lsi, xp, p->d_Lsx + p->xC, 0, p->d_loadmask, st);
+                                       p->d_Lsi, xp, p->d_Lsx + p->xC, 0, mask, s_);
             else
                 sf::launch_load_panels(p->d_Up, p->d_Ui, p->d_Ux, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,
-                                       p->d_Lsi, xp, p->d_Lsx + p->xC, 0, p->d_loadmask, st);
+                                       p->d_Lsi, xp, p->d_Lsx + p->xC, 0, mask, s_);
         }
+    };
+    if (first) {
+        HIP_TRY(hipMemsetAsync(p->d_info, 0, (1 + p->n_tickets) * sizeof(int), st));
+        if (p->xC > 0) HIP_TRY(hipMemsetAsync(p->d_Lsx, 0, (p->lu ? 2 : 1) * p->xC * sizeof(double), st));
+        // (out of core: the top panels only; every group assembles its own buffer when its turn comes, launch kind 7)
+        assemble(p->ooc_groups > 1 ? p->d_loadmask + (size_t)p->ooc_groups * (size_t)p->nsuper : p->d_loadmask, st);
     }
     mark();
     std::vector<int> kinds;
@@ -1557,6 +1664,23 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                 else sf::launch_potrf(p->d_potrf + L.first, L.count, p->d_Lsx, p->d_info, st);
                 break;
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, pc.pivinv, st); break;
+            case 7: {       // out of core: group L.first takes over buffer L.first & 1
+                const int g = (int)L.first;
+                if (g >= 2) {
+                    // ... once every piece of group g - 2 has LEFT the device (its DMA into the pinned ring is complete; the copy
+                    // workers count).  Everything group g - 2's pieces wait for has been enqueued and published by now.
+                    std::unique_lock<std::mutex> lk(p->dl_mu);
+                    p->dl_cv.wait(lk, [&] { return p->dl_abort || p->dl_group_left[(size_t)(g - 2)].load() <= 0; });
+                    if (p->dl_abort) return SF_ERR_HIP;
+                }
+                if (g >= 2 && p->ooc_buf > 0) {      // (the first factorization step zeroed everything: groups 0 and 1 find clean buffers)
+                    const size_t off = (size_t)(g & 1) * (size_t)p->ooc_buf, nb = (size_t)p->ooc_buf * sizeof(double);
+                    HIP_TRY(hipMemsetAsync(p->d_Lsx + off, 0, nb, st));
+                    if (p->lu) HIP_TRY(hipMemsetAsync(p->d_Lsx + p->xC + off, 0, nb, st));
+                }
+                assemble(p->d_loadmask + (size_t)g * (size_t)p->nsuper, st);
+                break;
+            }
             case 6: {       // k_update_small; a split launch (distributed top): this rank's share of the tiles (the update is a sum)
                 int64_t lo, hi;
                 launch_window(L, L.count, &lo, &hi);
@@ -2021,6 +2145,12 @@ static void dl_worker(sf_chol_plan* p, int w) {
     auto drain = [&](size_t k, int sl) -> bool {
         const DlPiece& pc = p->dl_pieces[k];
         if (hipEventSynchronize(p->dl_done[w][sl]) != hipSuccess) return false;
+        if (pc.group >= 0 && p->dl_group_left) {        // out of core: this piece has left the device
+            if (p->dl_group_left[(size_t)pc.group].fetch_sub(1) == 1) {
+                { std::lock_guard<std::mutex> g(p->dl_mu); }
+                p->dl_cv.notify_all();
+            }
+        }
         if (!p->dl_trace.empty()) p->dl_trace[3 * k + 1] = dl_now() - p->dl_t0;
         const double* ring = p->h_ring + ((int64_t)w * 2 + sl) * DL_SLOT;
         if (pc.s0 >= 0) {
@@ -2063,6 +2193,14 @@ static void dl_worker(sf_chol_plan* p, int w) {
         const DlPiece& pc = p->dl_pieces[k];
         {
             std::unique_lock<std::mutex> g(p->dl_mu);
+            if (prev < np && !(p->dl_abort || p->dl_published > (size_t)pc.ev)) {
+                // nothing to fetch yet: finish the piece in hand first (an out-of-core plan's enqueue thread may be waiting for
+                // exactly that piece before it publishes anything further)
+                g.unlock();
+                if (!drain(prev, prev_slot)) { dl_fail(p, SF_ERR_HIP); return; }
+                prev = np;
+                g.lock();
+            }
             p->dl_cv.wait(g, [&] { return p->dl_abort || p->dl_published > (size_t)pc.ev; });
             if (p->dl_abort) return;
         }
@@ -2158,6 +2296,10 @@ int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     p->dl_host = host_out;
     p->dl_next_ev = 0;
     p->dl_next_piece.store(0);
+    if (p->ooc_groups > 1) {
+        if (!p->dl_group_left) p->dl_group_left.reset(new std::atomic<int64_t>[(size_t)p->ooc_groups]);
+        for (int g = 0; g < p->ooc_groups; ++g) p->dl_group_left[(size_t)g].store(p->dl_group_pieces[(size_t)g]);
+    }
     p->dl_published = 0;
     p->dl_abort = false;
     p->dl_error.store(0);

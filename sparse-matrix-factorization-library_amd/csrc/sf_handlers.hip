@@ -433,7 +433,42 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
     for (HandlerState::Entry& e : S.cache)
         if (e.key == key) { plan = e.plan; e.stamp = ++S.clock; break; }
     if (!plan) {
+        // A factor that does not fit the device (or SF_DEVICE_BUDGET_MB, for tests and shared devices) is factorized OUT OF CORE:
+        // top panels resident, subtree groups streamed through two buffers while the finished ones travel to Lsx_out -- the role the
+        // reference gives its slot-sized stages (C:1721-1846, C:2421-2467).  Decided here, per pattern, before the plan is built.
+        std::vector<int32_t> ooc_group;
+        int ooc_ngroups = 1;
+        auto plan_ooc = [&](double shrink) -> int {
+            int64_t entries = 0;
+            for (sf_long s = 0; s < nsuper; ++s) entries += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
+            const int64_t per_entry = lu ? 16 : 8;
+            // everything a plan keeps on the device besides the panels, generously: values, structure, relative maps, task tables, rings
+            const int64_t overhead = 12 * (int64_t)Lp[n] + (lu && Up ? 12 * (int64_t)Up[n] : 0) + 24 * (int64_t)Lsip[nsuper] + ((int64_t)384 << 20);
+            int64_t budget = 0;
+            if (const char* env = getenv("SF_DEVICE_BUDGET_MB")) budget = (int64_t)strtoll(env, nullptr, 10) << 20;
+            if (budget <= 0) {
+                size_t fr = 0, tot = 0;
+                if (hipSetDevice(H.gpuIndex_physical) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return SF_ERR_HIP;
+                budget = (int64_t)fr - ((int64_t)1 << 30);
+            }
+            budget = (int64_t)((double)budget * shrink);
+            ooc_ngroups = 1;
+            if (entries * per_entry + overhead <= budget) return SF_OK;           // in core
+            const int64_t budget_entries = (budget - overhead) / per_entry;
+            if (budget_entries <= 0) return SF_ERR_ALLOC;
+            ooc_group.assign((size_t)std::max<sf_long>(nsuper, 1), 0);
+            int64_t ge = 0, te = 0, nd = 0;
+            const int rc = sf::ooc_partition(nsuper, Super, SuperMap, Lsip, Lsi, budget_entries, ooc_group.data(), &ooc_ngroups, &ge, &te, &nd);
+            if (trace || rc)
+                fprintf(stderr, "[sparseframe-hip] factorize: %.2f GB of panels against a device budget of %.2f GB -> out of core: %d groups, "
+                                "top %.2f GB resident + 2 buffers of %.2f GB%s\n", entries * per_entry / 1e9, budget / 1e9, ooc_ngroups,
+                        te * per_entry / 1e9, ge * per_entry / 1e9, rc == 2 ? " -- DOES NOT FIT" : "");
+            return rc == 0 ? SF_OK : (rc == 2 ? SF_ERR_ALLOC : SF_ERR_ARG);
+        };
         auto create = [&]() {
+            if (ooc_ngroups > 1)
+                return lu ? sf_lu_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, ooc_group.data(), ooc_ngroups)
+                          : sf_chol_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, ooc_group.data(), ooc_ngroups);
             return lu ? sf_lu_plan_create(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui)
                       : sf_chol_plan_create(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li);
         };
@@ -445,11 +480,19 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
             destroy_plan(S.cache[lru].plan);
             S.cache.erase(S.cache.begin() + lru);
         }
-        int rc = create();
+        int rc = plan_ooc(1.0);
+        if (rc == SF_OK) rc = create();
         if ((rc == SF_ERR_ALLOC || rc == SF_ERR_HIP) && !S.cache.empty()) {
             for (HandlerState::Entry& e : S.cache) destroy_plan(e.plan);
             S.cache.clear();
             (void)hipGetLastError();
+            rc = plan_ooc(1.0);
+            if (rc == SF_OK) rc = create();
+        }
+        // the estimate of what else lives on the device was too low (or somebody else took memory meanwhile): cut deeper, twice
+        for (double shrink = 0.8; rc == SF_ERR_ALLOC && shrink > 0.6; shrink -= 0.15) {
+            (void)hipGetLastError();
+            if (plan_ooc(shrink) != SF_OK) break;
             rc = create();
         }
         if (rc) return rc;
@@ -462,12 +505,15 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
     if (!rc) rc = sf_chol_plan_factorize_to_host(plan, Lx, Ux, Lsx_out);
     if (!rc && lu && PivOut) rc = sf_lu_plan_get_pivots(plan, PivOut);
     if (!rc && lu) note_perturbed(Lsx_out, plan->last_perturbed);
-    if (!rc) {
+    if (!rc && plan->ooc_groups <= 1) {        // (an out-of-core factor exists on the host only: its solves take the host sweep)
         Resident R;
         R.plan = plan;
         R.epoch = plan->epoch;
         std::lock_guard<std::mutex> g(g_res_mu);
         g_resident[(const void*)Lsx_out] = std::move(R);
+    } else if (!rc) {
+        std::lock_guard<std::mutex> g(g_res_mu);
+        g_resident.erase((const void*)Lsx_out);
     }
     if (trace) {
         const auto tk3 = std::chrono::steady_clock::now();

@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -107,6 +108,7 @@ struct DlPiece {
     // worker interleaves the columns into the reference layout (L:2514-2517).  s0 < 0: not an LU-direct piece.
     int32_t s0 = -1, s1 = -1;
     int64_t j0 = 0, dev_count = 0;
+    int32_t group = -1;     // out-of-core plans: the streamed group the piece belongs to (-1: a top panel)
 };
 
 struct sf_comm;      // one rank's end of a multi-GPU group (sf_multi.hip)
@@ -172,6 +174,12 @@ struct sf_chol_plan {
     bool partial = false;       // some supernodes are absent or the top panels are not loaded here
     int64_t top_off = 0, top_size = 0;   // contiguous region of the top panels inside one panel set
     size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
+    // out-of-core plan (plan_create, ooc_group): number of streamed groups (0: in core), entries of one of the two group buffers,
+    // pieces per group and how many of them are still on the device during a download
+    int ooc_groups = 0;
+    int64_t ooc_buf = 0;
+    std::vector<int64_t> dl_group_pieces;
+    std::unique_ptr<std::atomic<int64_t>[]> dl_group_left;
     int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches
     std::vector<Segment> segments;
     std::vector<uint32_t> all_masks;    // every group of the factorization (all ranks build the same sorted list)
@@ -255,7 +263,7 @@ struct sf_chol_plan {
 
     bool profiling = false;
     double last_ms = 0, last_load_ms = 0, last_panel_ms = 0, last_update_ms = 0;
-    double last_kind_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    double last_kind_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int last_status = SF_OK;
 
     // host copies needed by the device solve

@@ -1015,6 +1015,85 @@ int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Grouping for a factor that does not fit the device (the reference's answer to the same question is its slot-sized "stages"
+// streamed through the device, C:1721-1846 / C:2421-2467).  The supernodal tree is cut at a size S: every maximal
+// subtree of at most S panel entries is a unit, consecutive units (postorder) are packed into GROUPS of at most S entries, every
+// supernode above the cut is "top".  The numeric phase keeps the top panels resident for the whole factorization (they receive
+// the Schur updates of everything below them) and streams the groups through two alternating buffers of S entries: group g is
+// factorized while group g - 1 travels to the host.  Device need = top + 2 S (one group: top = 0, S = everything: in core).
+// The cut is the LARGEST S of a geometric ladder that fits `budget` entries -- fewest groups, smallest top.
+// group[s] in [0, *ngroups) or -1 (top).  Returns 0; 2 when no cut of the ladder fits (group[] then holds the cheapest one and
+// *need says what it would take).
+// ---------------------------------------------------------------------------------------------
+int ooc_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, int64_t budget,
+                  int32_t* group, int* ngroups, int64_t* group_entries, int64_t* top_entries, int64_t* need) {
+    if (nsuper < 0 || !group || !ngroups || (nsuper > 0 && (!Super || !SuperMap || !Lsip || !Lsi))) return 1;
+    std::vector<Long> par((size_t)nsuper, -1);
+    std::vector<int64_t> sz((size_t)nsuper, 0), sub((size_t)nsuper, 0);
+    int64_t total = 0;
+    for (Long s = 0; s < nsuper; ++s) {
+        const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+        sz[s] = (int64_t)nscol * nsrow;
+        total += sz[s];
+        if (nscol < nsrow) {
+            par[s] = SuperMap[Lsi[Lsip[s] + nscol]];
+            if (par[s] <= s || par[s] >= nsuper) return 1;      // postordered
+        }
+    }
+    for (Long s = 0; s < nsuper; ++s) {
+        sub[s] += sz[s];
+        if (par[s] >= 0) sub[par[s]] += sub[s];
+    }
+    constexpr int MAX_GROUPS = 4096;
+    // the cut at S: out = groups (nullptr: only count); returns top + (2 or 1) * largest group
+    auto cut = [&](int64_t S, int32_t* out, int* ng, int64_t* gmax, int64_t* top) {
+        int64_t t = 0, cur = 0, mx = 0;
+        int g = 0;
+        bool open = false;
+        for (Long s = 0; s < nsuper; ++s) {
+            if (sub[s] > S) { t += sz[s]; if (out) out[s] = -1; continue; }
+            const bool unit_root = par[s] < 0 || sub[par[s]] > S;
+            if (!unit_root) continue;
+            // the unit = supernodes (s - its descendants .. s]: a contiguous range of the postorder that ends at s
+            if (open && cur + sub[s] > S) { ++g; cur = 0; }
+            open = true;
+            cur += sub[s];
+            mx = std::max(mx, cur);
+            if (out) out[s] = g;
+        }
+        if (out)        // descendants take their unit root's group (parents come later in the postorder: walk down)
+            for (Long s = nsuper - 1; s >= 0; --s)
+                if (sub[s] <= S && par[s] >= 0 && sub[par[s]] <= S) out[s] = out[par[s]];
+        const int n_g = open ? g + 1 : 0;
+        if (ng) *ng = n_g;
+        if (gmax) *gmax = mx;
+        if (top) *top = t;
+        return t + (n_g > 1 ? 2 : 1) * mx;
+    };
+    int64_t bestS = total, best_need = total;       // everything in one group: in core
+    bool fits = total <= budget;
+    if (!fits) {
+        best_need = INT64_MAX;
+        double S = (double)budget / 2.0;
+        for (int it = 0; it < 96 && S >= 1.0; ++it, S *= 0.85) {
+            int ng = 0;
+            const int64_t nd = cut((int64_t)S, nullptr, &ng, nullptr, nullptr);
+            if (ng > MAX_GROUPS) break;
+            if (nd < best_need) { best_need = nd; bestS = (int64_t)S; }
+            if (nd <= budget) { best_need = nd; bestS = (int64_t)S; fits = true; break; }
+        }
+    }
+    int ng = 0;
+    int64_t gmax = 0, top = 0;
+    const int64_t nd = cut(bestS, group, &ng, &gmax, &top);
+    *ngroups = ng;
+    if (group_entries) *group_entries = gmax;
+    if (top_entries) *top_entries = top;
+    if (need) *need = nd;
+    return fits ? 0 : 2;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Built-in fill-reducing ordering for general patterns: nested dissection by BFS level structures.
 // (The reference calls METIS_NodeND, Cholesky/Source/SparseFrame.c:942, a third-party library; this is NOT a
 // restatement of METIS -- it is a self-contained stand-in so that SparseFrame_analyze is usable without a caller-

@@ -91,6 +91,10 @@ double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems
 int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi,
                       int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction, double top_weight = 1.0);
 
+// out-of-core grouping (sf_symbolic.cpp): group[s] = streamed group of supernode s or -1 (resident top); 0 = fits `budget` panel entries
+int ooc_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, int64_t budget,
+                  int32_t* group, int* ngroups, int64_t* group_entries, int64_t* top_entries, int64_t* need);
+
 int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm);
 
 int grid_nd_perm(Long nx, Long ny, Long nz, Long leaf, Long sepw, Long* perm);

@@ -1,0 +1,230 @@
+"""A factor larger than the device budget (the reference's answer: slot-sized stages streamed through the device, the factor on the
+host, C:1721-1846 / C:2421-2467; here: whole subtree groups through two alternating buffers under a resident top -- DESIGN 7b).
+CPU: the grouping and the schedule of an out-of-core plan.  GPU: its factor against the oracle, through the flat C ABI and through
+SparseFrame_factorize with a lowered budget (SF_DEVICE_BUDGET_MB)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import sf, gen, nd_perm_py, rel_err
+
+TOL_FACTOR = 1e-12
+TOL_RESIDUAL = 1e-13
+
+
+def panel_entries(S):
+    return np.diff(S.Super) * np.diff(S.Lsip)
+
+
+def parents(S):
+    ns = int(S.nsuper)
+    par = np.full(ns, -1, dtype=np.int64)
+    nscol, nsrow = np.diff(S.Super), np.diff(S.Lsip)
+    for s in range(ns):
+        if nscol[s] < nsrow[s]:
+            par[s] = S.SuperMap[S.Lsi[S.Lsip[s] + nscol[s]]]
+    return par
+
+
+def chol_cases():
+    out = []
+    N = 20
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    out.append(("lap3d_20", n, Cp, Ci, Cx, nd_perm_py(N, N, N), 1 << 30))
+    n, Cp, Ci, Cx = gen.stencil_spd_lower(90, 90)
+    out.append(("stencil2d_90", n, Cp, Ci, Cx, sf.grid_nd_perm(90, 90, 1, 3, 2), sf.REFERENCE_SLOT_1GPU))
+    # a forest: three independent grids (no top at all above the trees' roots)
+    n1, Cp1, Ci1, Cx1 = gen.laplacian_lower(9, 9, 9)
+    k = 3
+    Cp = np.concatenate([[0]] + [Cp1[1:] + i * Cp1[-1] for i in range(k)]).astype(np.int64)
+    Ci = np.concatenate([Ci1 + i * n1 for i in range(k)]).astype(np.int64)
+    Cx = np.concatenate([Cx1 * (1 + i) for i in range(k)])
+    p1 = np.asarray(nd_perm_py(9, 9, 9))
+    out.append(("forest_3x9cubed", k * n1, Cp, Ci, Cx, np.concatenate([p1 + i * n1 for i in range(k)]), 1 << 30))
+    return out
+
+
+@pytest.mark.parametrize("case", chol_cases(), ids=lambda c: c[0])
+def test_grouping_properties(case):
+    """groups are whole subtrees, consecutive in the postorder; the top is closed upwards; the reported need is top + 2 x largest
+    group and it fits the budget whenever the call says so; a budget that holds everything gives one group"""
+    name, n, Cp, Ci, Cx, perm, slot = case
+    S = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    ent, par = panel_entries(S), parents(S)
+    total = int(ent.sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, total)
+    assert fits and ng == 1 and te == 0 and nd == total and (g == 0).all()
+    seen_cut = False
+    for frac in (0.9, 0.75, 0.6, 0.45, 0.3):
+        g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * frac))
+        assert ng >= 2
+        seen_cut = True
+        top = g < 0
+        assert int(ent[top].sum()) == te
+        sizes = np.bincount(g[~top], weights=ent[~top], minlength=ng).astype(np.int64)
+        assert sizes.max() == ge and nd == te + 2 * ge
+        assert (not fits) or nd <= int(total * frac)
+        for s in range(int(S.nsuper)):
+            if par[s] >= 0:
+                assert top[par[s]] or g[par[s]] == g[s], "a group is a union of whole subtrees"
+                assert not (top[s] and not top[par[s]]), "the top is closed upwards"
+        # consecutive in the postorder: group numbers never decrease along the supernode order
+        gg = g[~top]
+        assert (np.diff(gg) >= 0).all()
+        assert set(np.unique(gg)) == set(range(ng))
+    assert seen_cut
+
+
+@pytest.mark.parametrize("case", chol_cases(), ids=lambda c: c[0])
+def test_schedule_of_an_out_of_core_plan(case):
+    """without a device: one (zero + assemble) launch per group, in group order, each before the first launch that touches the group;
+    the groups' panels alias two buffers of the largest group's size, the top panels follow; the plan's byte count is what the
+    partition promised (+ the plan's tables)"""
+    name, n, Cp, Ci, Cx, perm, slot = case
+    S = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    ent = panel_entries(S)
+    total = int(ent.sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.6))
+    sch = sf.Schedule(S, None, 0, 1, ooc_group=g, ooc_ngroups=ng)
+    lt = sch.launch_table()
+    k7 = np.nonzero(lt[:, 0] == 7)[0]
+    assert len(k7) == ng
+    xp = sch.panel_offsets(S.nsuper)
+    for s in range(int(S.nsuper)):
+        if g[s] >= 0:
+            b = (g[s] & 1) * ge
+            assert b <= xp[s] and xp[s] + ent[s] <= b + ge
+        else:
+            assert 2 * ge <= xp[s] and xp[s] + ent[s] <= 2 * ge + te
+    # inside one group (and inside the top) panels do not overlap
+    for grp in list(range(ng)) + [-1]:
+        idx = np.nonzero(g == grp)[0]
+        o = np.argsort(xp[idx])
+        a, e = xp[idx][o], ent[idx][o]
+        assert (a[1:] >= a[:-1] + e[:-1]).all()
+    in_core = sf.Schedule(S, None, 0, 1, ooc_group=np.zeros(S.nsuper, dtype=np.int32), ooc_ngroups=1)
+    saved = in_core.stat("bytes_device") - sch.stat("bytes_device")
+    # (one assembly mask per group is the only table an out-of-core plan adds; it has no solve schedule)
+    assert saved >= 8 * (total - nd) - (ng + 1) * int(S.nsuper) - 64
+    sch.close()
+    in_core.close()
+
+
+# ------------------------------------------------------------------ GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frac", [0.75, 0.45])
+@pytest.mark.parametrize("case", chol_cases(), ids=lambda c: c[0])
+def test_out_of_core_cholesky_matches_the_oracle(oracle, case, frac):
+    name, n, Cp, Ci, Cx, perm, slot = case
+    S = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * frac))
+    assert ng >= 2
+    plan = sf.CholPlan(S, ooc_group=g, ooc_ngroups=ng)
+    assert plan.stat("bytes_device") < 8 * total + 64 * len(S.Lsi) or nd >= total      # the factor is not resident as a whole
+    ref, info, _ = oracle.chol_factorize(S)
+    assert info == 0
+    mask = oracle.lower_mask(S)
+    for rep in range(2):                            # the second run finds both buffers used
+        out = np.full(S.xsize, np.nan)
+        plan.factorize_to_host(S.Lx, out=out)
+        assert not np.isnan(out[mask]).any()
+        assert rel_err(out, ref, mask) <= TOL_FACTOR
+        res, _ = oracle.chol_residual(S, np.where(mask, out, 0.0))
+        assert res <= TOL_RESIDUAL
+    # the factor never exists on the device as a whole: everything that needs it there refuses
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
+        plan.factorize()
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
+        plan.solve(np.ones(n))
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_out_of_core_with_many_small_groups(oracle, monkeypatch):
+    """more groups than copy workers, 1 MiB staging slots (several pieces per group), a wide root: every buffer is re-used many
+    times and the launch that re-uses it has to wait for the copy of the group before the last"""
+    monkeypatch.setenv("SF_DL_SLOT_MB", "1")
+    N = 26
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N), 4 << 30)
+    assert np.diff(S.Super).max() > 512
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.05))        # (does not "fit": the cheapest cut of the ladder, small groups)
+    assert ng >= 24
+    plan = sf.CholPlan(S, ooc_group=g, ooc_ngroups=ng)
+    out = np.full(S.xsize, np.nan)
+    plan.factorize_to_host(S.Lx, out=out)
+    ref, info, _ = oracle.chol_factorize(S)
+    mask = oracle.lower_mask(S)
+    assert rel_err(out, ref, mask) <= TOL_FACTOR
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tol", [0.0, 0.1])
+def test_out_of_core_lu_matches_the_oracle(oracle, tol):
+    """LU: both panels of a group alias the two buffers (L and U^T halves); with threshold pivoting inside the blocks (the matrix
+    of the large fixture whose permuted diagonal has zeros: rows really are interchanged)"""
+    if tol > 0:
+        import golden_large
+        c = golden_large.build_case("piv_zero_diag_12")
+        n, S = c["n"], c["sym"]
+    else:
+        N = 16
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=5)
+        S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(N, N, N), 1 << 30, "lu", False)
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.5))
+    assert ng >= 2
+    plan = sf.LUPlan(S, ooc_group=g, ooc_ngroups=ng)
+    if tol > 0:
+        plan.set_pivoting(tol)
+    out = np.full(S.xsize, np.nan)
+    plan.factorize_to_host(S.Lx, S.Ux, out=out)
+    assert not np.isnan(out).any()
+    if tol > 0:
+        ref, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=tol)
+        assert info == 0 and np.array_equal(plan.get_pivots(), pivpos)
+        assert np.count_nonzero(pivpos != np.arange(n)) > 0
+    else:
+        ref, info, _ = oracle.lu_factorize(S)
+        assert info == 0
+    assert rel_err(out, ref) <= (1e-10 if tol > 0 else TOL_FACTOR)
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_struct_entry_point_goes_out_of_core_under_a_budget(oracle, monkeypatch):
+    """SparseFrame_factorize with a device budget smaller than the factor: same Lsx, plan cached per pattern, the solve answers from
+    the host copy (nothing resident to solve with); without the budget the same handler list factorizes in core again"""
+    N = 24
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    perm = nd_perm_py(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
+    ref, info, _ = oracle.chol_factorize(S)
+    mask = oracle.lower_mask(S)
+    total_mb = 8 * int(panel_entries(S).sum()) / 2**20
+    # the budget counts the plan's tables and staging rings too (384 MiB + structure): leave the panels 60 % of their size
+    overhead_mb = 384 + (12 * int(S.Lp[-1]) + 24 * len(S.Lsi)) / 2**20
+    monkeypatch.setenv("SF_DEVICE_BUDGET_MB", str(int(overhead_mb + 0.6 * total_mb)))
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    builds0 = common.plan_builds()
+    solves0 = sf.lib.sf_handlers_resident_solves()
+    for scale in (1.0, 2.0):
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx * scale)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        C.memset(mi.c.Lsx, 0xff, 8 * S.xsize)
+        mi.factorize(common)
+        got = mi.array("Lsx", S.xsize).copy()
+        assert not np.isnan(got[mask]).any()
+        assert rel_err(got, ref * np.sqrt(scale), mask) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    assert common.plan_builds() == builds0 + 1                      # one out-of-core plan for both calls
+    assert sf.lib.sf_handlers_resident_solves() == solves0          # host sweep: no resident factor
+    common.close()
