@@ -97,6 +97,41 @@ def end_to_end_case(sf, np, N=128):
             "cleanup_s": round(t6 - t5, 3), "end_to_end_s": round(t6 - t1, 3), "residual": res}
 
 
+def half_log_det(np, sym, Lsx):
+    """sum of the logarithms of the Cholesky factor's diagonal, from the factor in the reference layout"""
+    sm, Sup, Xp = np.asarray(sym.SuperMap), np.asarray(sym.Super), np.asarray(sym.Lsxp)[:-1]
+    nsrow = np.diff(sym.Lsip)
+    return float(np.log(Lsx[Xp[sm] + (np.arange(sym.n) - Sup[sm]) * (nsrow[sm] + 1)]).sum())
+
+
+def out_of_core_case(sf, np, sym, fraction=0.55, in_core_log_det=None):
+    """the headline matrix with the device budget lowered to `fraction` of its factor: top panels resident, subtree
+    groups streamed through two buffers, the factor leaves for pageable host memory as it is finished -- the same entry point and
+    destination as pcie_inclusive.plan_second_call_ms, which is the in-core figure to compare with"""
+    ent = np.diff(sym.Super) * np.diff(sym.Lsip)
+    total = int(ent.sum())
+    group, ng, ge, te, need, fits = sf.ooc_partition(sym, int(total * fraction))
+    plan = sf.CholPlan(sym, ooc_group=group, ooc_ngroups=ng)
+    host = np.empty(max(sym.xsize, 1), dtype=np.float64)
+    ms = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        plan.factorize_to_host(sym.Lx, host)
+        ms.append((time.perf_counter() - t0) * 1e3)
+    dev = plan.stat("bytes_device")
+    plan.close()
+    # the factor only exists on the host (the struct path answers solves with its host sweep: minutes at this size).  The parity of the
+    # out-of-core path is tests/test_out_of_core.py (oracle, SparseFrame's own validate); here: log det against the in-core run's
+    ld = half_log_det(np, sym, host)
+    del host
+    return {"workload": f"the headline matrix, device budget {fraction} x factor", "groups": int(ng), "fits_budget": bool(fits),
+            "factor_bytes": 8 * total, "device_bytes": int(dev), "top_bytes": 8 * int(te), "group_buffer_bytes": 8 * int(ge),
+            "first_call_ms": round(ms[0], 1), "second_call_ms": round(ms[1], 1),
+            "GFLOPs_struct_second_call": round(sym.flops_struct / (ms[1] * 1e-3) / 1e9, 1),
+            "log_det_half": ld, "log_det_half_in_core": in_core_log_det,
+            "log_det_rel_difference": (abs(ld - in_core_log_det) / abs(in_core_log_det)) if in_core_log_det else None}
+
+
 def hbm_roofline_whole_factorization(plan, sym, ms):
     """HBM roofline of a whole (scatter-bound, config 3) factorization: algorithmic bytes = memset + loadA
     (16 nnz + 8 xsize) + every panel read and written once by its factorization (16 xsize) + read once as an update source
@@ -592,6 +627,8 @@ def main():
             ms = [timed(lambda: plan.factorize_to_host(sym.Lx, sym.Ux, host)) for _ in range(2)]
         else:
             ms = [timed(lambda: plan.factorize_to_host(sym.Lx, host)) for _ in range(2)]
+        if not lu:      # sum of log(diagonal of L): compared with the out-of-core run's below (secondary.out_of_core)
+            pc["log_det_half"] = half_log_det(np, sym, host)
         del host
         pc.update({"plan_first_call_ms": round(ms[0], 1), "plan_second_call_ms": round(ms[1], 1),
                    "factor_bytes": int(sym.xsize) * 8,
@@ -619,6 +656,7 @@ def main():
                             "config5_pivoting": secondary_case(sf, np, "config5_pivoting")}
         plan.close()            # (the 30 GB of the headline plan make room; nothing below uses it)
         plan = None
+        out["secondary"]["out_of_core"] = out_of_core_case(sf, np, sym, in_core_log_det=out["config"].get("pcie_inclusive", {}).get("log_det_half"))
         out["secondary"]["end_to_end"] = end_to_end_case(sf, np, N)
 
     if args.cpu_grid < 0:
