@@ -280,24 +280,45 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         ~JoinAlloc() { if (t.joinable()) t.join(); if (mem) (void)hipFree(mem); e.release(); }
     } join_alloc{factor_alloc, factor_mem, early};
     // ---------------- validate the structure the kernels index with ----------------
-    for (sf_long s = 0; s < nsuper; ++s) {
-        const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
-        const sf_long want = lu ? nscol * (2 * nsrow - nscol) : nscol * nsrow;
-        if (nscol <= 0 || nsrow < nscol || Lsxp[s + 1] - Lsxp[s] != want || nsrow >= (sf_long)0x7fffffff) {
-            delete p;
-            return SF_ERR_ARG;
+    {
+        // (row indices and SuperMap: 10^8 entries at 128^3 -- a few threads over ranges of supernodes; the pointer arrays first, alone)
+        std::atomic<bool> bad{false};
+        for (sf_long s = 0; s < nsuper; ++s) {
+            const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+            const sf_long want = lu ? nscol * (2 * nsrow - nscol) : nscol * nsrow;
+            if (nscol <= 0 || nsrow < nscol || Lsxp[s + 1] - Lsxp[s] != want || nsrow >= (sf_long)0x7fffffff || Lsip[s] < 0) bad = true;
         }
-        for (sf_long k = 0; k < nsrow; ++k) {
-            const sf_long g = Lsi[Lsip[s] + k];
-            const bool ok = (k < nscol) ? (g == Super[s] + k) : (g > Lsi[Lsip[s] + k - 1] && g < n);
-            if (!ok) { delete p; return SF_ERR_ARG; }
+        if (bad || Super[0] != 0 || Super[nsuper] != n) { delete p; return SF_ERR_ARG; }
+        auto check_range = [&](sf_long s0, sf_long s1) {
+            for (sf_long s = s0; s < s1 && !bad.load(std::memory_order_relaxed); ++s) {
+                const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
+                for (sf_long k = 0; k < nsrow; ++k) {
+                    const sf_long g = Lsi[Lsip[s] + k];
+                    const bool ok = (k < nscol) ? (g == Super[s] + k) : (g > Lsi[Lsip[s] + k - 1] && g < n);
+                    if (!ok) { bad = true; return; }
+                }
+                // SuperMap indexes level[] / phase[] below: it must be the inverse of Super (foreign arrays: checked, not trusted)
+                for (sf_long j = Super[s]; j < Super[s + 1]; ++j)
+                    if (SuperMap[j] != s) { bad = true; return; }
+            }
+        };
+        const int64_t work = (int64_t)Lsip[nsuper] + n;
+        const int T = work < (1 << 22) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+        if (T == 1) check_range(0, nsuper);
+        else {
+            std::vector<std::thread> th;
+            sf_long s0 = 0;
+            for (int t = 0; t < T; ++t) {       // equal shares of the row-index array
+                const int64_t upto = (int64_t)Lsip[nsuper] * (t + 1) / T;
+                sf_long s1 = (t == T - 1) ? nsuper : (sf_long)(std::upper_bound(Lsip + s0, Lsip + nsuper, (sf_long)upto) - Lsip);
+                s1 = std::min(std::max(s1, s0), nsuper);
+                th.emplace_back(check_range, s0, s1);
+                s0 = s1;
+            }
+            for (std::thread& t : th) t.join();
         }
+        if (bad) { delete p; return SF_ERR_ARG; }
     }
-    if (Super[0] != 0 || Super[nsuper] != n) { delete p; return SF_ERR_ARG; }
-    // SuperMap indexes level[] / phase[] below: it must be the inverse of Super (foreign arrays: checked, not trusted)
-    for (sf_long s = 0; s < nsuper; ++s)
-        for (sf_long j = Super[s]; j < Super[s + 1]; ++j)
-            if (SuperMap[j] != s) { delete p; return SF_ERR_ARG; }
 
     // ---------------- levels of the supernodal tree ----------------
     std::vector<int> level(nsuper, 0);
@@ -315,10 +336,15 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     p->level_of = level;
     // sharding consistency: every row of a stored supernode must belong to a stored supernode (its updates have
     // a local target), and a top supernode only has top ancestors
-    for (sf_long s = 0; s < nsuper; ++s) {
+    for (sf_long s = 0; s < nsuper && (phase_in || ooc); ++s) {         // (nothing to check when every supernode is simply stored: 10^8 row indices at 128^3)
         if (p->phase[s] < 0) continue;
         const sf_long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
         for (sf_long k = nscol; k < nsrow; ++k) {
+            // out of core: a streamed supernode only updates panels of its own group (alive in the same buffer) or of the resident top
+            if (ooc && ooc_group[s] >= 0) {
+                const int32_t ga = ooc_group[SuperMap[Lsi[Lsip[s] + k]]];
+                if (ga >= 0 && ga != ooc_group[s]) { delete p; return SF_ERR_ARG; }
+            }
             const int8_t pa = p->phase[SuperMap[Lsi[Lsip[s] + k]]];
             if (pa < 0 || (p->phase[s] == 1 && pa != 1)) { delete p; return SF_ERR_ARG; }
         }
@@ -954,7 +980,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // one staging slot, larger runs cut into slot-sized pieces.  Top panels of a sharded plan are identical on every
     // rank once factored: their pieces are dealt out over the ranks so that every PCIe link carries a share.
     {
-        if (const char* env = getenv("SF_DL_WORKERS")) p->dl_workers = std::max(1, std::min(DL_WORKERS_MAX, atoi(env)));
+        if (const char* env = getenv("SF_DL_WORKERS")) p->dl_workers = p->dl_workers_fresh = std::max(1, std::min(DL_WORKERS_MAX, atoi(env)));
         if (const char* env = sf_exp_env("SF_DL_HOST_WAIT")) p->dl_host_wait = atoi(env) != 0;
         if (const char* env = getenv("SF_DL_SLOT_MB")) p->dl_slot = (int64_t)std::max(1, atoi(env)) << 17;
         const int64_t DL_SLOT = p->dl_slot;
@@ -2275,13 +2301,13 @@ int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     HIP_TRY(hipSetDevice(p->device));
     if (p->dl_cpus_known == 0) dl_lookup_cpus(p);
     if (!p->h_ring) {
-        const size_t rb = (size_t)p->dl_workers * 2 * p->dl_slot * sizeof(double);
+        const size_t rb = (size_t)std::max(p->dl_workers, p->dl_workers_fresh) * 2 * p->dl_slot * sizeof(double);
         HIP_TRY(hipHostMalloc((void**)&p->h_ring, rb, hipHostMallocDefault));
         if (p->lu && !p->dl_lu_direct) {
             HIP_TRY(hipMalloc((void**)&p->d_ring, rb));
             p->bytes_device += rb;
         }
-        for (int w = 0; w < p->dl_workers; ++w) {
+        for (int w = 0; w < std::max(p->dl_workers, p->dl_workers_fresh); ++w) {
             HIP_TRY(hipStreamCreateWithFlags(&p->dl_streams[w], hipStreamNonBlocking));
             for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&p->dl_done[w][k], hipEventDisableTiming));
         }
@@ -2310,7 +2336,23 @@ int sf_dl_begin(sf_chol_plan* p, double* host_out) {
     p->dl_trace.clear();
     if (getenv("SF_DL_TRACE")) p->dl_trace.assign(3 * p->dl_pieces.size(), 0.0);
     p->dl_t0 = dl_now();
-    const int nw = (int)std::min<size_t>(p->dl_workers, p->dl_pieces.size());
+    // A destination whose pages have never been touched (the first call after SparseFrame_analyze malloc'ed Lsx) makes every worker's
+    // memcpy fault its pages in as it goes, and 4 workers no longer keep up with the factorization: 6 bring the first struct call at
+    // 128^3 from 714 to 662 ms; on touched pages 4 are enough and 6 only share hardware queues (sf_plan_internal.h).  mincore() on a
+    // sample of the destination's pages tells the two apart.
+    int nw_call = p->dl_workers;
+    if (p->dl_workers_fresh > nw_call && p->xsize > (int64_t)(64 << 20)) {
+        const long pg = sysconf(_SC_PAGESIZE);
+        int resident = 0, probed = 0;
+        for (int k = 0; k < 16 && pg > 0; ++k) {
+            const uintptr_t a = ((uintptr_t)(host_out + (p->xsize / 16) * k + p->xsize / 32)) & ~((uintptr_t)pg - 1);
+            unsigned char vec = 0;
+            if (mincore((void*)a, (size_t)pg, &vec) == 0) { ++probed; resident += vec & 1; }
+        }
+        if (probed > 0 && 2 * resident < probed) nw_call = p->dl_workers_fresh;
+    }
+    p->dl_workers_last = nw_call;
+    const int nw = (int)std::min<size_t>(nw_call, p->dl_pieces.size());
     for (int w = 0; w < nw; ++w) p->dl_threads.emplace_back(dl_worker, p, w);
     // (First touch of a just-malloc'ed destination is left to the copy workers.  Helper threads that populate the page tables ahead
     // of them -- MADV_POPULATE_WRITE over the array in address order -- were measured and make the first call SLOWER: 637 ms of

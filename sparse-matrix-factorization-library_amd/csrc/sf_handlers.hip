@@ -521,7 +521,7 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
         fprintf(stderr, "[sparseframe-hip] factorize: pattern hash %.1f ms, plan lookup/build %.1f ms, H2D + numeric + overlapped D2H %.1f ms\n",
                 ms(tk0, tk1), ms(tk1, tk2), ms(tk2, tk3));
         fprintf(stderr, "[sparseframe-hip]   copy workers %s, last on CPUs", plan->dl_cpus_known == 1 ? "confined to the device's NUMA node" : "not confined");
-        for (int w = 0; w < plan->dl_workers; ++w) fprintf(stderr, " %d", plan->dl_last_cpu[w]);
+        for (int w = 0; w < plan->dl_workers_last; ++w) fprintf(stderr, " %d", plan->dl_last_cpu[w]);
         fprintf(stderr, "\n");
     }
     return rc;

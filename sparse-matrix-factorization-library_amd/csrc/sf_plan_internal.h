@@ -93,6 +93,7 @@ constexpr int DL_WORKERS_DEFAULT = 4;                   // copy workers: own HIP
                                                         // queues the runtime gives the ordinary-priority streams: with 6 two pairs of
                                                         // workers share a queue and the struct call at 128^3 takes 553-603 ms instead of
                                                         // 552-568 (profiles/r02_f_struct_slow_mode.txt, part 5)
+constexpr int DL_WORKERS_FRESH = 6;
 constexpr int DL_WORKERS_MAX = 16;                      // SF_DL_WORKERS / SF_DL_SLOT_MB (read at plan creation) tune both
 struct DlPiece {
     int64_t dev_off, host_off, count;   // doubles; LU: dev_off unused (the piece is packed from the (L, U^T) panels)
@@ -132,6 +133,8 @@ struct sf_chol_plan {
     double* d_ring = nullptr;                   // LU: device staging of packed pieces, same shape
     int64_t dl_slot = DL_SLOT_DEFAULT;
     int dl_workers = DL_WORKERS_DEFAULT;
+    int dl_workers_fresh = DL_WORKERS_FRESH;    // ... when the destination's pages have never been touched (sf_dl_begin)
+    int dl_workers_last = 0;                    // workers of the last download
     hipStream_t dl_streams[DL_WORKERS_MAX] = {};
     // LU direct download: before a piece's event is recorded, the upper triangle (with the diagonal) of its columns' part of the
     // supernode's diagonal block is filled into the L panel from the U^T panel (k_lu_fill_u11), so that the L panel holds the

@@ -173,12 +173,12 @@ def test_out_of_core_lu_matches_the_oracle(oracle, tol):
         c = golden_large.build_case("piv_zero_diag_12")
         n, S = c["n"], c["sym"]
     else:
-        N = 16
-        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, seed=5)
-        S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(N, N, N), 1 << 30, "lu", False)
+        N = 20          # (no random long-range entries: they leave no subtree to stream, the whole tree is "top")
+        n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, extra_per_row=0, drop=0.2, seed=5)
+        S = sf.analyze(n, Cp, Ci, Cx, sf.grid_nd_perm(N, N, N, 3, 2), 1 << 30, "lu", False)
     total = int(panel_entries(S).sum())
-    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.5))
-    assert ng >= 2
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.7))
+    assert ng >= 2 and (tol > 0 or (fits and ng >= 6))
     plan = sf.LUPlan(S, ooc_group=g, ooc_ngroups=ng)
     if tol > 0:
         plan.set_pivoting(tol)
@@ -228,3 +228,82 @@ def test_struct_entry_point_goes_out_of_core_under_a_budget(oracle, monkeypatch)
     assert common.plan_builds() == builds0 + 1                      # one out-of-core plan for both calls
     assert sf.lib.sf_handlers_resident_solves() == solves0          # host sweep: no resident factor
     common.close()
+
+
+@pytest.mark.gpu
+def test_lu_struct_entry_point_under_a_budget(oracle, monkeypatch):
+    """the LU library's SparseFrame_factorize under a budget: packed (L \\ U) panels assembled by the copy workers from the two
+    aliased halves, value by value against the oracle; the second call finds the cached out-of-core plan"""
+    N = 20
+    n, Cp, Ci, Cx = gen.unsymmetric_stencil(N, N, N, extra_per_row=0, drop=0.2, seed=3)
+    perm = sf.grid_nd_perm(N, N, N, 3, 2)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30, "lu", False)
+    total_mb = 16 * int(panel_entries(S).sum()) / 2**20
+    overhead_mb = 384 + (12 * int(S.Lp[-1]) + 12 * int(S.Up[-1]) + 24 * len(S.Lsi)) / 2**20
+    monkeypatch.setenv("SF_DEVICE_BUDGET_MB", str(int(overhead_mb + 0.72 * total_mb)))
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    builds0 = common.plan_builds()
+    for scale in (1.0, 3.0):
+        mi = sf.LUMatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx * scale, symmetric=False)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        C.memset(mi.c.Lsx, 0xff, 8 * S.xsize)
+        mi.factorize(common)
+        got = mi.array("Lsx", S.xsize).copy()
+        assert not np.isnan(got).any()
+        S2 = sf.analyze(n, Cp, Ci, Cx * scale, perm, 1 << 30, "lu", False)
+        ref, info, _ = oracle.lu_factorize(S2)
+        assert info == 0 and rel_err(got, ref) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    assert common.plan_builds() == builds0 + 1
+    common.close()
+
+
+@pytest.mark.gpu
+def test_a_budget_below_the_resident_top_is_an_allocation_error(monkeypatch, capfd):
+    """no cut of the tree fits: SparseFrame_factorize fails with SF_ERR_ALLOC and says what it would have taken; nothing is written,
+    nothing crashes, and the same handler list factorizes the matrix once the budget is lifted"""
+    N = 20
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    perm = nd_perm_py(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
+    total_mb = 8 * int(panel_entries(S).sum()) / 2**20
+    overhead_mb = 384 + (12 * int(S.Lp[-1]) + 24 * len(S.Lsi)) / 2**20
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    mi = sf.MatrixInfo()
+    mi.set_csc(n, Cp, Ci, Cx)
+    mi.set_perm(perm)
+    mi.analyze(common)
+    monkeypatch.setenv("SF_DEVICE_BUDGET_MB", str(int(overhead_mb + 0.2 * total_mb)))
+    with pytest.raises(sf.SparseFrameError):
+        mi.factorize(common)
+    assert "DOES NOT FIT" in capfd.readouterr().err
+    monkeypatch.delenv("SF_DEVICE_BUDGET_MB")
+    mi.factorize(common)
+    assert mi.validate() <= TOL_RESIDUAL
+    mi.cleanup()
+    common.close()
+
+
+def test_a_grouping_that_splits_a_subtree_is_refused():
+    """foreign group arrays are checked, not trusted: a streamed supernode whose ancestor sits in ANOTHER group would update a panel
+    that is not on the device any more (or not yet) -- plan creation refuses (no device needed: the schedule-only entry point)"""
+    N = 12
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(N, N, N), 1 << 30)
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.7))
+    assert ng >= 2
+    par = parents(S)
+    bad = g.copy()
+    s = next(s for s in range(int(S.nsuper)) if g[s] >= 0 and par[s] >= 0 and g[par[s]] == g[s])
+    bad[s] = (g[s] + 1) % ng                       # a child in another group than its parent
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
+        sf.Schedule(S, None, 0, 1, ooc_group=bad, ooc_ngroups=ng)
+    bad = g.copy()
+    t = next(s for s in range(int(S.nsuper)) if g[s] < 0 and par[s] >= 0)
+    bad[par[t]] = 0                                # a resident supernode below a streamed one
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
+        sf.Schedule(S, None, 0, 1, ooc_group=bad, ooc_ngroups=ng)
