@@ -481,6 +481,13 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
             S.cache.erase(S.cache.begin() + lru);
         }
         int rc = plan_ooc(1.0);
+        if ((rc != SF_OK || ooc_ngroups > 1) && !S.cache.empty() && !getenv("SF_DEVICE_BUDGET_MB")) {
+            // the free memory the decision saw did not count what the cached plans hold: they go first, then the decision is taken again
+            for (HandlerState::Entry& e : S.cache) destroy_plan(e.plan);
+            S.cache.clear();
+            (void)hipDeviceSynchronize();
+            rc = plan_ooc(1.0);
+        }
         if (rc == SF_OK) rc = create();
         if ((rc == SF_ERR_ALLOC || rc == SF_ERR_HIP) && !S.cache.empty()) {
             for (HandlerState::Entry& e : S.cache) destroy_plan(e.plan);

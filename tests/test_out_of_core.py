@@ -307,3 +307,44 @@ def test_a_grouping_that_splits_a_subtree_is_refused():
     bad[par[t]] = 0                                # a resident supernode below a streamed one
     with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
         sf.Schedule(S, None, 0, 1, ooc_group=bad, ooc_ngroups=ng)
+
+
+@pytest.mark.gpu
+def test_struct_entry_point_goes_out_of_core_when_the_device_is_full(oracle, monkeypatch, capfd):
+    """no budget variable: most of the device is taken by somebody else (a torch tensor), what is left holds about 60 % of the
+    factor -- SparseFrame_factorize has to notice by itself (hipMemGetInfo), stream the factor and still deliver the same Lsx"""
+    import torch
+    monkeypatch.delenv("SF_DEVICE_BUDGET_MB", raising=False)
+    monkeypatch.setenv("SF_TRACE", "1")
+    N = 40
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    perm = sf.grid_nd_perm(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
+    ref, info, _ = oracle.chol_factorize(S)
+    mask = oracle.lower_mask(S)
+    panels = 8 * int(panel_entries(S).sum())
+    overhead = (384 << 20) + 12 * int(S.Lp[-1]) + 24 * len(S.Lsi)
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+    torch.cuda.init()
+    free, total = torch.cuda.mem_get_info(0)
+    want_free = (1 << 30) + overhead + int(0.6 * panels)
+    ballast = torch.empty(max(free - want_free, 0), dtype=torch.uint8, device="cuda:0")
+    try:
+        free2, _ = torch.cuda.mem_get_info(0)
+        assert free2 < (1 << 30) + overhead + panels, (free2, want_free)        # the in-core plan can not fit
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        C.memset(mi.c.Lsx, 0xff, 8 * S.xsize)
+        mi.factorize(common)
+        err = capfd.readouterr().err
+        assert "out of core" in err and "DOES NOT FIT" not in err, err[-2000:]
+        got = mi.array("Lsx", S.xsize).copy()
+        assert rel_err(got, ref, mask) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        mi.cleanup()
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
+        common.close()
