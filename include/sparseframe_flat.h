@@ -351,6 +351,11 @@ int sf_handlers_allocate(struct common_info_struct *common_info, struct gpu_info
 int sf_handlers_free(struct common_info_struct *common_info, struct gpu_info_struct **gpu_info_list_ptr);
 /* device plans built so far by the handlers of a list (a repeated sparsity pattern must not add to it) */
 int64_t sf_handlers_plan_builds(struct gpu_info_struct *gpu_info_list, int n_handlers);
+/* The device pool of handler d (allocated once in SparseFrame_allocate_gpu, where the reference allocates its eight device slots,
+ * C:92-283: min(8 x devSlotSize, a quarter of the device); SF_DEVICE_POOL_MB overrides, 0 = none; one-matrix-per-handler lists only).
+ * The handler lends it to the plan of ONE cached pattern at a time for its factor, so that the first SparseFrame_factorize of a
+ * pattern does not start with a hipMalloc of tens of GB.  out[0] = bytes, out[1] = 1 while lent, out[2] = n of the borrowing plan. */
+int sf_handlers_pool_info(struct gpu_info_struct *list, int d, sf_long *out);
 int sf_handlers_factorize(struct common_info_struct *common_info, struct gpu_info_struct *gpu_info_list, int lu, int serial,
                           sf_long n, sf_long nsuper, const sf_long *Super, const sf_long *SuperMap,
                           const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,

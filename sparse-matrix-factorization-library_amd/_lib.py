@@ -106,6 +106,8 @@ lib.sf_test_inject_failure.argtypes = [C.c_int, C.c_int]
 lib.sf_test_inject_failure.restype = None
 lib.sf_handlers_set_resident_solve.argtypes = [C.c_int]
 lib.sf_handlers_set_resident_solve.restype = C.c_int
+lib.sf_handlers_pool_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+lib.sf_handlers_pool_info.restype = C.c_int
 lib.sf_handlers_resident_solves.argtypes = []
 lib.sf_handlers_resident_solves.restype = C.c_int64
 lib.sf_handlers_fingerprint_fallbacks.argtypes = []

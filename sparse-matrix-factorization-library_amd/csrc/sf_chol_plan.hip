@@ -66,6 +66,15 @@ size_t sf_reference_slot_size(int ndev, size_t min_mem) {
     return m;
 }
 
+// The NEXT plan this thread creates may place its factor in a buffer of the caller's instead of allocating one (the struct path's
+// per-handler pool, sf_handlers.hip: the reference allocates its device slots once, in SparseFrame_allocate_gpu, C:92-283 -- so does
+// the pool; a 30 GB hipMalloc inside the first SparseFrame_factorize of a pattern costs 12 - 790 ms depending on the box's state).
+// The offer is consumed by that one plan_create whether or not the buffer is large enough (sf_plan_factor_borrowed tells).
+static thread_local double* t_offer_ptr = nullptr;
+static thread_local size_t t_offer_bytes = 0;
+void sf_plan_offer_factor_buffer(double* ptr, size_t bytes) { t_offer_ptr = ptr; t_offer_bytes = bytes; }
+int sf_plan_factor_borrowed(const sf_chol_plan* p) { return p && p->factor_borrowed ? 1 : 0; }
+
 int sf_chol_plan_destroy(sf_chol_plan* p) {
     if (!p) return SF_OK;
     if (p->dry) { delete p; return SF_OK; }
@@ -74,7 +83,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
                     p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_status, p->d_fill, p->d_solveT, p->d_solveT_list};
     for (void* q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q && !(q == (void*)p->d_Lsx && p->factor_borrowed)) (void)hipFree(q);      // (a borrowed factor buffer goes back to its lender)
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->ev_s0) (void)hipEventDestroy(p->ev_s0);
@@ -243,6 +252,9 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // past the last panel.
     const size_t xb_factor = (std::max<int64_t>((lu ? 2 : 1) * p->xC, 1) + 2) * sizeof(double);
     hipError_t factor_alloc_err = hipSuccess;
+    double* const lent = (!dry && t_offer_ptr && t_offer_bytes >= xb_factor) ? t_offer_ptr : nullptr;
+    t_offer_ptr = nullptr; t_offer_bytes = 0;
+    p->factor_borrowed = lent != nullptr;
     double* factor_mem = nullptr;           // handed to the plan once everything else has succeeded; freed by the guard otherwise
     // ... and, behind the allocation, the device copies of the symbolic structure (narrowed to 32-bit indices on the way): 150 MB of
     // host loops and pageable H2D copies at 128^3 that depend on the inputs only, i.e. ~35 ms of the first call of a pattern that now
@@ -259,10 +271,10 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         }
     } early;
     const sf_long nnz_in = Lp[n], isize_in = Lsip[nsuper];
-    std::thread factor_alloc([&factor_alloc_err, &factor_mem, &early, xb_factor, device, dry, n, nsuper, nnz_in, isize_in, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li] {
+    std::thread factor_alloc([&factor_alloc_err, &factor_mem, &early, lent, xb_factor, device, dry, n, nsuper, nnz_in, isize_in, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li] {
         if (dry) return;
         factor_alloc_err = hipSetDevice(device);
-        if (factor_alloc_err == hipSuccess) factor_alloc_err = hipMalloc((void**)&factor_mem, xb_factor);
+        if (factor_alloc_err == hipSuccess && !lent) factor_alloc_err = hipMalloc((void**)&factor_mem, xb_factor);
         if (factor_alloc_err != hipSuccess) return;
         auto narrow = [](const sf_long* a, sf_long len) { std::vector<int32_t> v((size_t)std::max<sf_long>(len, 0)); for (sf_long k = 0; k < len; ++k) v[(size_t)k] = (int32_t)a[k]; return v; };
         int rc = SF_OK;
@@ -1339,7 +1351,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         const size_t xb = xb_factor, vb = std::max<int64_t>(p->nnz, 1) * sizeof(double);
         if (factor_alloc.joinable()) factor_alloc.join();
         if (factor_alloc_err != hipSuccess) { (void)hipGetLastError(); rc = SF_ERR_ALLOC; break; }
-        p->d_Lsx = factor_mem;
+        p->d_Lsx = lent ? lent : factor_mem;
         factor_mem = nullptr;
         if (!dalloc((void**)&p->d_Lx, vb) ||
             !dalloc((void**)&p->d_info, (1 + p->n_tickets) * sizeof(int))) { rc = SF_ERR_ALLOC; break; }

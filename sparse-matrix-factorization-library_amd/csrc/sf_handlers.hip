@@ -207,8 +207,21 @@ struct HandlerState {
     uint64_t clock = 0;
     uint64_t builds = 0;                // plans built by this handler (cache misses)
     MultiState* multi = nullptr;        // handler 0 only
+    // Device pool: ONE buffer allocated in SparseFrame_allocate_gpu (where the reference allocates its eight slots, C:92-283) that
+    // the handler lends to the plan of one pattern at a time for its factor -- so that the first SparseFrame_factorize of a pattern
+    // does not start with a hipMalloc of tens of GB (12 - 790 ms, depending on what the box did before).  A factor that does not
+    // fit the pool, or a second cached pattern, allocates as before; a multi-handler factorization gives the pools back first.
+    int device = 0;
+    double* pool = nullptr;
+    size_t pool_bytes = 0;
+    sf_chol_plan* pool_user = nullptr;
+    void release_pool() {
+        if (pool && !pool_user) { (void)hipSetDevice(device); (void)hipFree(pool); pool = nullptr; pool_bytes = 0; }
+    }
     ~HandlerState() {
         for (Entry& e : cache) destroy_plan(e.plan);
+        pool_user = nullptr;
+        release_pool();
         delete multi;
     }
 };
@@ -360,6 +373,21 @@ int sf_handlers_allocate(struct common_info_struct* common, struct gpu_info_stru
     if (ndev > 0 && min_mem != (size_t)-1) {
         common->devSlotSize = sf_reference_slot_size(ndev, min_mem);
         common->minDevMemSize = common->devSlotSize * 8;
+        // the pool: what the reference's eight slots would take (at most a quarter of the device); SF_DEVICE_POOL_MB overrides, 0 = none.
+        // One handler per physical device only (not for emulated handlers sharing a device), and only where one handler = one matrix:
+        // with several handlers the default is ONE matrix over all of them, whose per-rank plans need the memory themselves.
+        size_t want = std::min(common->devSlotSize * 8, min_mem / 4);
+        if (const char* env = getenv("SF_DEVICE_POOL_MB")) want = (size_t)strtoull(env, nullptr, 10) << 20;
+        const char* mode = getenv("SF_MULTI");
+        const bool per_matrix = ndev == 1 || (mode && strcmp(mode, "matrix") == 0);
+        for (int d = 0; d < ndev && want > 0 && ndev == nphys && per_matrix; ++d) {
+            HandlerState* st = (*list)[d].st;
+            if (!st) continue;
+            st->device = (*list)[d].gpuIndex_physical;
+            void* q = nullptr;
+            if (hipSetDevice(st->device) == hipSuccess && hipMalloc(&q, want) == hipSuccess) { st->pool = (double*)q; st->pool_bytes = want; }
+            else (void)hipGetLastError();
+        }
     } else {
         const char* env = getenv("SF_DEVSLOT");
         common->devSlotSize = env ? (size_t)strtoull(env, nullptr, 10) : ((size_t)1 << 30);
@@ -380,6 +408,16 @@ int64_t sf_handlers_plan_builds(struct gpu_info_struct* list, int n_handlers) {
         if (list[d].st->multi) total += (int64_t)list[d].st->multi->builds;
     }
     return total;
+}
+
+// the device pool of handler d: out[0] = bytes (0: none), out[1] = 1 while a plan's factor lives in it, out[2] = that plan's n
+int sf_handlers_pool_info(struct gpu_info_struct* list, int d, sf_long* out) {
+    if (!list || d < 0 || !out || !list[d].st) return SF_ERR_ARG;
+    std::lock_guard<std::mutex> guard(list[d].st->mu);
+    out[0] = (sf_long)list[d].st->pool_bytes;
+    out[1] = list[d].st->pool_user ? 1 : 0;
+    out[2] = list[d].st->pool_user ? list[d].st->pool_user->n : 0;
+    return SF_OK;
 }
 
 int sf_handlers_free(struct common_info_struct* common, struct gpu_info_struct** list) {
@@ -450,6 +488,8 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
                 size_t fr = 0, tot = 0;
                 if (hipSetDevice(H.gpuIndex_physical) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return SF_ERR_HIP;
                 budget = (int64_t)fr - ((int64_t)1 << 30);
+                // (the factor of an in-core plan goes into the handler's idle pool if it fits there: counted as free for exactly that)
+                if (S.pool && !S.pool_user && (size_t)(entries * per_entry + 16) <= S.pool_bytes) budget += entries * per_entry + 16;
             }
             budget = (int64_t)((double)budget * shrink);
             ooc_ngroups = 1;
@@ -466,6 +506,12 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
             return rc == 0 ? SF_OK : (rc == 2 ? SF_ERR_ALLOC : SF_ERR_ARG);
         };
         auto create = [&]() {
+            const bool offered = S.pool && !S.pool_user;
+            if (offered) sf_plan_offer_factor_buffer(S.pool, S.pool_bytes);
+            struct Claim {      // whoever got the buffer is its user until it is dropped
+                HandlerState& S; sf_chol_plan*& plan; bool offered;
+                ~Claim() { sf_plan_offer_factor_buffer(nullptr, 0); if (offered && plan && sf_plan_factor_borrowed(plan)) S.pool_user = plan; }
+            } claim{S, plan, offered};
             if (ooc_ngroups > 1)
                 return lu ? sf_lu_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, ooc_group.data(), ooc_ngroups)
                           : sf_chol_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, ooc_group.data(), ooc_ngroups);
@@ -473,25 +519,38 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
                       : sf_chol_plan_create(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li);
         };
         // make room first when the cache is full; when the device is out of memory, drop everything cached and retry once
+        auto drop = [&](sf_chol_plan* q) { if (S.pool_user == q) S.pool_user = nullptr; destroy_plan(q); };
         while (S.cache.size() >= MAX_CACHED_PLANS) {
             size_t lru = 0;
             for (size_t i = 1; i < S.cache.size(); ++i)
                 if (S.cache[i].stamp < S.cache[lru].stamp) lru = i;
-            destroy_plan(S.cache[lru].plan);
+            drop(S.cache[lru].plan);
             S.cache.erase(S.cache.begin() + lru);
         }
         int rc = plan_ooc(1.0);
         if ((rc != SF_OK || ooc_ngroups > 1) && !S.cache.empty() && !getenv("SF_DEVICE_BUDGET_MB")) {
             // the free memory the decision saw did not count what the cached plans hold: they go first, then the decision is taken again
-            for (HandlerState::Entry& e : S.cache) destroy_plan(e.plan);
+            for (HandlerState::Entry& e : S.cache) drop(e.plan);
             S.cache.clear();
             (void)hipDeviceSynchronize();
             rc = plan_ooc(1.0);
         }
+        if ((rc != SF_OK || ooc_ngroups > 1) && S.pool && !S.pool_user && !getenv("SF_DEVICE_BUDGET_MB")) {
+            // ... and so does the idle pool when the factor is too large for it: the memory serves the plan better directly
+            S.release_pool();
+            rc = plan_ooc(1.0);
+        }
         if (rc == SF_OK) rc = create();
         if ((rc == SF_ERR_ALLOC || rc == SF_ERR_HIP) && !S.cache.empty()) {
-            for (HandlerState::Entry& e : S.cache) destroy_plan(e.plan);
+            for (HandlerState::Entry& e : S.cache) drop(e.plan);
             S.cache.clear();
+            (void)hipGetLastError();
+            rc = plan_ooc(1.0);
+            if (rc == SF_OK) rc = create();
+        }
+        if ((rc == SF_ERR_ALLOC || rc == SF_ERR_HIP) && S.pool && !S.pool_user) {
+            // the pool itself is in the way (a factor larger than the pool, on a device that holds little else): give it back for good
+            S.release_pool();
             (void)hipGetLastError();
             rc = plan_ooc(1.0);
             if (rc == SF_OK) rc = create();

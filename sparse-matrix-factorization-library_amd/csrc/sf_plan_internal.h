@@ -112,6 +112,10 @@ struct DlPiece {
     int32_t group = -1;     // out-of-core plans: the streamed group the piece belongs to (-1: a top panel)
 };
 
+// struct path's device pool (sf_handlers.hip): the next plan_create of this thread may use `ptr` for its factor
+extern "C" void sf_plan_offer_factor_buffer(double* ptr, size_t bytes);
+extern "C" int sf_plan_factor_borrowed(const sf_chol_plan* p);
+
 struct sf_comm;      // one rank's end of a multi-GPU group (sf_multi.hip)
 struct sf_chol_plan;
 // one step of the solve sweeps (sf_chol_plan.hip; shared by sf_chol_plan_solve and sf_chol_plan_solve_distributed)
@@ -179,6 +183,7 @@ struct sf_chol_plan {
     size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
     // out-of-core plan (plan_create, ooc_group): number of streamed groups (0: in core), entries of one of the two group buffers,
     // pieces per group and how many of them are still on the device during a download
+    bool factor_borrowed = false;       // d_Lsx is a buffer the creator lent (sf_plan_offer_factor_buffer): never freed here
     int ooc_groups = 0;
     int64_t ooc_buf = 0;
     std::vector<int64_t> dl_group_pieces;

@@ -315,6 +315,7 @@ def test_struct_entry_point_goes_out_of_core_when_the_device_is_full(oracle, mon
     factor -- SparseFrame_factorize has to notice by itself (hipMemGetInfo), stream the factor and still deliver the same Lsx"""
     import torch
     monkeypatch.delenv("SF_DEVICE_BUDGET_MB", raising=False)
+    monkeypatch.setenv("SF_DEVICE_POOL_MB", "0")        # (the handler's own pool would hold this small factor)
     monkeypatch.setenv("SF_TRACE", "1")
     N = 40
     n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
@@ -348,3 +349,38 @@ def test_struct_entry_point_goes_out_of_core_when_the_device_is_full(oracle, mon
         del ballast
         torch.cuda.empty_cache()
         common.close()
+
+
+@pytest.mark.gpu
+def test_the_handler_pool_lends_its_buffer_to_one_pattern_at_a_time(oracle, monkeypatch):
+    """SparseFrame_allocate_gpu allocates the device pool (as the reference allocates its slots there); the first pattern's plan
+    places its factor in it, a second pattern cached beside it allocates its own, and when the first is evicted (third pattern: two
+    plans are cached per handler) the pool is lent again.  Results are those of plans with their own buffers."""
+    monkeypatch.setenv("SF_DEVICE_POOL_MB", "512")
+    common = sf.CommonInfo(dev_slot_size=1 << 30)
+
+    def pool():
+        out = (C.c_int64 * 3)()
+        assert sf.lib.sf_handlers_pool_info(common.gpu_list, 0, out) == 0
+        return list(out)
+
+    assert pool() == [512 << 20, 0, 0]
+    users = []
+    for N in (14, 16, 18, 14):
+        n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+        perm = nd_perm_py(N, N, N)
+        S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
+        ref, info, _ = oracle.chol_factorize(S)
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        mi.factorize(common)
+        assert rel_err(mi.array("Lsx", S.xsize).copy(), ref, oracle.lower_mask(S)) <= TOL_FACTOR
+        assert mi.validate() <= TOL_RESIDUAL
+        users.append(pool()[2])
+        mi.cleanup()
+    # pattern 1 borrows; pattern 2 finds the pool taken; pattern 3 evicts pattern 1 (least recently used) and borrows; pattern 4 (= 1
+    # again, rebuilt) evicts pattern 2 and allocates its own: the pool stays with pattern 3
+    assert users == [14 ** 3, 14 ** 3, 18 ** 3, 18 ** 3]
+    common.close()
