@@ -1922,7 +1922,7 @@ int sf_plan_import_from(sf_chol_plan* dst, sf_chol_plan* const* parts, int npart
     if (!dst || dst->partial || !parts || nparts < 1) return SF_ERR_ARG;
     for (int r = 0; r < nparts; ++r) {
         const sf_chol_plan* P = parts[r];
-        if (!P || P->n != dst->n || P->nsuper != dst->nsuper || P->lu != dst->lu) return SF_ERR_ARG;
+        if (!P || P->n != dst->n || P->nsuper != dst->nsuper || P->lu != dst->lu || P->ooc_groups > 1) return SF_ERR_ARG;
         HIP_TRY(hipSetDevice(P->device));
         HIP_TRY(hipStreamSynchronize(P->stream));
     }
@@ -2431,6 +2431,7 @@ int sf_chol_plan_top_region(sf_chol_plan* p, void** dptr, sf_long* count) {
 int sf_chol_plan_get_factor(sf_chol_plan* p, sf_float* Lsx) {
     if (!p || (!Lsx && p->xsize > 0)) return SF_ERR_ARG;
     if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
+    if (p->ooc_groups > 1) return SF_ERR_ARG;       // an out-of-core plan's factor never exists on the device as a whole
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->xsize <= 0) return SF_OK;
@@ -2491,7 +2492,7 @@ int sf_chol_plan_get_factor_range(sf_chol_plan* p, sf_long e_begin, sf_long e_en
 }
 
 int sf_plan_panel_hashes(sf_chol_plan* p, const uint64_t** out) {
-    if (!p || !out) return SF_ERR_ARG;
+    if (!p || !out || p->ooc_groups > 1) return SF_ERR_ARG;
     if (p->hash_epoch != p->epoch || p->h_hash.size() != (size_t)std::max<int64_t>(p->nsuper, 1)) {
         if (p->dry) return SF_ERR_ARG;        // a schedule-only plan has no device side
         HIP_TRY(hipSetDevice(p->device));

@@ -139,6 +139,8 @@ def test_out_of_core_cholesky_matches_the_oracle(oracle, case, frac):
         plan.factorize()
     with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
         plan.solve(np.ones(n))
+    with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
+        plan.get_factor()
     plan.close()
 
 
