@@ -1318,7 +1318,10 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 // The updated 64 x 64 tile then goes to LDS (U[column][row]) where the POTRF wave / the blocked solve picks it up.
 // ---------------------------------------------------------------------------------------------------
 #ifndef SF_LU_STEP_WGS
-#define SF_LU_STEP_WGS 3      // workgroups per CU the LU variant of k_step is compiled for (168 VGPRs; the throughput-bound launches of the lower levels want the third)
+#define SF_LU_STEP_WGS 3
+#ifndef SF_POTRF_PW
+#define SF_POTRF_PW 16        // columns per panel of the fused step's 64 x 64 POTRF (16 or 32; 32 measured slower, see k_step)
+#endif      // workgroups per CU the LU variant of k_step is compiled for (168 VGPRs; the throughput-bound launches of the lower levels want the third)
 #endif
 constexpr int ST_ULD = ST_ROWS + 1;      // LDS column stride of the updated tile U[c][r]
 constexpr int ST_KC = 32;                // K chunk of the update's LDS-staged operand
@@ -1729,15 +1732,21 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
         // Trailing part: every wave updates its 16 rows of the columns to the right with MFMA out of LDS,
         //   U[cj][ci] -= sum_k L(cj,k) L(ci,k),  k in the panel  (A operand = -L rows cj, B operand = L rows ci)
         bool bad = false;
+        // PW columns per panel.  32 = two panels per block instead of four -- half the barriers and trailing passes on the step's
+        // critical path, at the price of more of the elimination in the broadcast form (496 instead of 120 (column, column) pairs per
+        // panel) -- was measured (round 4) and is SLOWER: the panel becomes issue-bound on its v_readlane / v_fma pairs; config 3
+        // 11.6 ms against 11.2 (fused steps 5.4 against 5.0), 128^3 fused steps 58.0 against 55.7 ms.
+        constexpr int PW = SF_POTRF_PW;
 #pragma unroll
-        for (int q = 0; q < NB / 16; ++q) {
-            const int c0 = q * 16;
+        for (int q = 0; q < NB / PW; ++q) {
+            const int c0 = q * PW;
             if (wave == 0) {
-                double a[16];
+                double a[PW];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) a[u] = U[(c0 + u) * ST_ULD + lane];
+                for (int u = 0; u < PW; ++u) a[u] = U[(c0 + u) * ST_ULD + lane];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < PW; ++j) {
+                    if (PW > 16 && j == 16 && c0 + 16 >= b) break;          // narrow block: the rest of the panel is identity padding
                     const double djj = readlane_f64(a[j], c0 + j);
                     bad = bad || !(djj > 0.0);
                     double rinv = __builtin_amdgcn_rsq(djj);
@@ -1747,28 +1756,28 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                     const double lj = (lane == c0 + j) ? d : ((lane > c0 + j) ? a[j] * rinv : 0.0);
                     a[j] = lj;
 #pragma unroll
-                    for (int c = j + 1; c < 16; ++c) a[c] -= lj * readlane_f64(lj, c0 + c);
+                    for (int c = j + 1; c < PW; ++c) a[c] -= lj * readlane_f64(lj, c0 + c);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < PW; ++u) {
                     U[(c0 + u) * ST_ULD + lane] = a[u];
                     if (lane < b && c0 + u <= lane) Ag[lane + (int64_t)(c0 + u) * ld] = a[u];
                 }
             }
-            if (q == NB / 16 - 1 || c0 + 16 >= b) break;      // nothing but identity padding to the right (narrow panel)
+            if (q == NB / PW - 1 || c0 + PW >= b) break;      // nothing but identity padding to the right (narrow panel)
             __syncthreads();
-            if (wave > q) {
+            if (16 * wave >= c0 + PW) {
                 const int ci = wave * 16 + fr;                  // this wave's 16 rows
-                double lf[4];
+                double lf[PW / 4];
 #pragma unroll
-                for (int sgm = 0; sgm < 4; ++sgm) lf[sgm] = U[(c0 + 4 * sgm + fk) * ST_ULD + ci];            // B[k][j = ci]
-                for (int ct = q + 1; ct <= wave; ++ct) {
+                for (int sgm = 0; sgm < PW / 4; ++sgm) lf[sgm] = U[(c0 + 4 * sgm + fk) * ST_ULD + ci];            // B[k][j = ci]
+                for (int ct = (c0 + PW) / 16; ct <= wave; ++ct) {
                     const int cb = ct * 16;
                     double4_t d;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d[r] = U[(cb + fk + 4 * r) * ST_ULD + ci];                    // D[i = cj][j = ci]
 #pragma unroll
-                    for (int sgm = 0; sgm < 4; ++sgm)
+                    for (int sgm = 0; sgm < PW / 4; ++sgm)
                         d = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(c0 + 4 * sgm + fk) * ST_ULD + cb + fr], lf[sgm], d, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) U[(cb + fk + 4 * r) * ST_ULD + ci] = d[r];
