@@ -54,6 +54,46 @@ def test_config2_laplacian_128cubed_properties():
     plan.close()
 
 
+def test_config2_out_of_core_128cubed_properties():
+    """config 2 with the device budget at 55 % of the factor: the struct entry points end to end -- SparseFrame_factorize
+    picks the out-of-core plan, Lsx arrives on the host, validate (host sweep: nothing is resident) -- and the closed-form log det"""
+    import os
+    N = 128
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    perm = sf.grid_nd_perm(N, N, N, 3, 1)
+    sym = sf.analyze(n, Cp, Ci, Cx, perm, sf.REFERENCE_SLOT_1GPU)
+    panels = 8 * int((np.diff(sym.Super) * np.diff(sym.Lsip)).sum())
+    overhead = (384 << 20) + 12 * int(sym.Lp[-1]) + 24 * len(sym.Lsi)
+    old = os.environ.get("SF_DEVICE_BUDGET_MB")
+    os.environ["SF_DEVICE_BUDGET_MB"] = str((overhead + int(0.55 * panels)) >> 20)
+    try:
+        common = sf.CommonInfo(dev_slot_size=sf.REFERENCE_SLOT_1GPU)
+        mi = sf.MatrixInfo()
+        mi.set_csc(n, Cp, Ci, Cx)
+        mi.set_perm(perm)
+        mi.analyze(common)
+        solves0 = sf.lib.sf_handlers_resident_solves()
+        mi.factorize(common)
+        Lsx = mi.array("Lsx", sym.xsize)
+        c = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
+        logdet = float(np.sum(np.log(6.0 - c[:, None, None] - c[None, :, None] - c[None, None, :])))
+        cols = np.arange(n)
+        s = sym.SuperMap[cols]
+        nsrow = (sym.Lsip[1:] - sym.Lsip[:-1])[s]
+        d = Lsx[sym.Lsxp[s] + (cols - sym.Super[s]) * (nsrow + 1)]
+        assert np.all(d > 0)
+        assert abs(2.0 * float(np.sum(np.log(d))) - logdet) <= 1e-11 * abs(logdet)
+        assert mi.validate() <= 1e-13
+        assert sf.lib.sf_handlers_resident_solves() == solves0          # the host sweep answered
+        mi.cleanup()
+        common.close()
+    finally:
+        if old is None:
+            os.environ.pop("SF_DEVICE_BUDGET_MB", None)
+        else:
+            os.environ["SF_DEVICE_BUDGET_MB"] = old
+
+
 def test_config3_stencil2d_1000_properties():
     g = 1000
     n, Cp, Ci, Cx = gen.stencil_spd_lower(g, g)
