@@ -3,7 +3,7 @@ fraction of the factor, next to the in-core plan of the same matrix (same entry 
     python tools/ooc_timing.py [N=128] [fractions=0.6,0.4,0.25] [repeats=2]
 One JSON line per configuration: groups, resident top / buffer sizes, device bytes of the plan, wall time of the call, residual."""
 import importlib, json, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 sf = importlib.import_module("sparse-matrix-factorization-library_amd")
 gen = importlib.import_module("sparse-matrix-factorization-library_amd.gen")
