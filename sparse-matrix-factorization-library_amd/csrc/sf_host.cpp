@@ -1,6 +1,7 @@
 // Host side of the C ABI: the reference's struct-based entry points (matrix set-up, analysis,
 // triangular solve, validation, clean-up) and the flat sf_symbolic_* accessors.
 // Reference files: Cholesky/Source/SparseFrame.c (C:), Cholesky/Include/info.h (I:).
+#include "sf_host_solve.h"
 #include <sparseframe_hip.h>
 
 #include <algorithm>
@@ -422,6 +423,17 @@ int SparseFrame_solve_supernodal(struct matrix_info_struct* mi) {
     const Long ns = mi->nsuper;
     double* x = mi->Xx;
     memcpy(x, mi->Bx, mi->nrow * sizeof(double));
+    // a large factor: the same two sweeps on several threads (sf_host_solve.h); the scalar sweep below is the reference's (C:3036-3139)
+    if (const int T = sf_host_solve::threads_for((sf_host_solve::Long)mi->xsize); T > 1) {
+        std::vector<int32_t> owner((size_t)(ns > 0 ? ns : 1), 0);
+        // (the top is shared by all threads: a top flop costs 1 / T of a subtree flop, plus the barriers)
+        if (sf_subtree_partition_weighted(ns, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi, T, 1.0 / T + 0.05, owner.data(), nullptr, nullptr) == SF_OK) {
+            sf_host_solve::solve_parallel<false>(mi->nrow, ns, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi, mi->Lsxp, mi->Lsx, nullptr,
+                                                 owner.data(), T, x);
+            mi->solveTime = wall_seconds() - t0;
+            return 0;
+        }
+    }
     for (Long s = 0; s < ns; ++s) {
         const Long nscol = mi->Super[s + 1] - mi->Super[s];
         const Long nsrow = mi->Lsip[s + 1] - mi->Lsip[s];

@@ -1,6 +1,7 @@
 // libsparseframe_lu_hip.so: the reference's struct-based entry points over the LU layout of matrix_info_struct
 // (LU/Include/info.h), forwarding to the flat ABI of libsparseframe_hip.so (sf_symbolic_create_lu, sf_lu_plan_*).
 // Reference file: LU/Source/SparseFrame.c ("L:").
+#include "sf_host_solve.h"
 #include <sparseframe_lu_hip.h>
 
 #include <algorithm>
@@ -303,6 +304,17 @@ int SparseFrame_solve_supernodal(struct matrix_info_struct* mi) {
     }
     double* x = mi->Xx;
     memcpy(x, mi->Bx, mi->nrow * sizeof(double));
+    // a large factor: the same two sweeps on several threads (sf_host_solve.h); the scalar sweep below is the reference's (L:3592-3700)
+    if (const int T = sf_host_solve::threads_for((sf_host_solve::Long)mi->xsize); T > 1) {
+        std::vector<int32_t> owner((size_t)(mi->nsuper > 0 ? mi->nsuper : 1), 0);
+        // (the top is shared by all threads: a top flop costs 1 / T of a subtree flop, plus the barriers)
+        if (sf_subtree_partition_weighted(mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi, T, 1.0 / T + 0.05, owner.data(), nullptr, nullptr) == SF_OK) {
+            sf_host_solve::solve_parallel<true>(mi->nrow, mi->nsuper, mi->Super, mi->SuperMap, mi->Lsip, mi->Lsi, mi->Lsxp, mi->Lsx, mi->PivInv,
+                                                owner.data(), T, x);
+            mi->solveTime = wall_seconds() - t0;
+            return 0;
+        }
+    }
     for (sf_long s = 0; s < mi->nsuper; ++s) {
         const sf_long nscol = mi->Super[s + 1] - mi->Super[s], nsrow = mi->Lsip[s + 1] - mi->Lsip[s], lda = 2 * nsrow - nscol;
         const sf_long* rows = mi->Lsi + mi->Lsip[s];
