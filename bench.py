@@ -104,7 +104,7 @@ def half_log_det(np, sym, Lsx):
     return float(np.log(Lsx[Xp[sm] + (np.arange(sym.n) - Sup[sm]) * (nsrow[sm] + 1)]).sum())
 
 
-def out_of_core_case(sf, np, sym, fraction=0.55, in_core_log_det=None):
+def out_of_core_case(sf, np, sym, fraction=0.55, in_core_log_det=None, inputs=None):
     """the headline matrix with the device budget lowered to `fraction` of its factor: top panels resident, subtree
     groups streamed through two buffers, the factor leaves for pageable host memory as it is finished -- the same entry point and
     destination as pcie_inclusive.plan_second_call_ms, which is the in-core figure to compare with"""
@@ -120,11 +120,35 @@ def out_of_core_case(sf, np, sym, fraction=0.55, in_core_log_det=None):
         ms.append((time.perf_counter() - t0) * 1e3)
     dev = plan.stat("bytes_device")
     plan.close()
-    # the factor only exists on the host (the struct path answers solves with its host sweep: minutes at this size).  The parity of the
-    # out-of-core path is tests/test_out_of_core.py (oracle, SparseFrame's own validate); here: log det against the in-core run's
+    # the factor only exists on the host.  The parity of the out-of-core path is tests/test_out_of_core.py (oracle, SparseFrame's own
+    # validate); here: log det against the in-core run's
     ld = half_log_det(np, sym, host)
     del host
-    return {"workload": f"the headline matrix, device budget {fraction} x factor", "groups": int(ng), "fits_budget": bool(fits),
+    # ... and the reference's entry points under the same budget: SparseFrame_factorize decides for the out-of-core plan by itself,
+    # SparseFrame_validate solves on the host (nothing is resident; threaded sweeps over Lsx, csrc/sf_host_solve.h)
+    struct = None
+    if inputs:
+        overhead = (384 << 20) + 12 * int(sym.Lp[-1]) + 24 * len(sym.Lsi)
+        old_budget = os.environ.get("SF_DEVICE_BUDGET_MB")
+        os.environ["SF_DEVICE_BUDGET_MB"] = str((overhead + int(fraction * 8 * total)) >> 20)
+        try:
+            common = sf.CommonInfo(dev_slot_size=sf.REFERENCE_SLOT_1GPU)
+            mi = sf.MatrixInfo()
+            mi.set_csc(inputs["n"], inputs["Cp"], inputs["Ci"], inputs["Cx"])
+            mi.set_perm(inputs["perm"])
+            mi.analyze(common)
+            mi.factorize(common)
+            res = mi.validate()
+            struct = {"factorize_first_call_ms": round(1e3 * mi.c.factorizeTime, 1), "validate_residual": res,
+                      "host_solve_ms": round(1e3 * mi.c.solveTime, 1)}
+            mi.cleanup()
+            common.close()
+        finally:
+            if old_budget is None:
+                os.environ.pop("SF_DEVICE_BUDGET_MB", None)
+            else:
+                os.environ["SF_DEVICE_BUDGET_MB"] = old_budget
+    return {"struct_entry_points": struct, "workload": f"the headline matrix, device budget {fraction} x factor", "groups": int(ng), "fits_budget": bool(fits),
             "factor_bytes": 8 * total, "device_bytes": int(dev), "top_bytes": 8 * int(te), "group_buffer_bytes": 8 * int(ge),
             "first_call_ms": round(ms[0], 1), "second_call_ms": round(ms[1], 1),
             "GFLOPs_struct_second_call": round(sym.flops_struct / (ms[1] * 1e-3) / 1e9, 1),
@@ -656,7 +680,7 @@ def main():
                             "config5_pivoting": secondary_case(sf, np, "config5_pivoting")}
         plan.close()            # (the 30 GB of the headline plan make room; nothing below uses it)
         plan = None
-        out["secondary"]["out_of_core"] = out_of_core_case(sf, np, sym, in_core_log_det=out["config"].get("pcie_inclusive", {}).get("log_det_half"))
+        out["secondary"]["out_of_core"] = out_of_core_case(sf, np, sym, in_core_log_det=out["config"].get("pcie_inclusive", {}).get("log_det_half"), inputs=inputs)
         out["secondary"]["end_to_end"] = end_to_end_case(sf, np, N)
 
     if args.cpu_grid < 0:
