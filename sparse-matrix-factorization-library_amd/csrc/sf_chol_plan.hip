@@ -84,6 +84,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
                     p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_status, p->d_fill, p->d_solveT, p->d_solveT_list};
     for (void* q : ptrs)
         if (q && !(q == (void*)p->d_Lsx && p->factor_borrowed)) (void)hipFree(q);      // (a borrowed factor buffer goes back to its lender)
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->ev_s0) (void)hipEventDestroy(p->ev_s0);
@@ -423,6 +424,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
     // rank's own rounding.  Everything a chain reads is either an all-reduced sum or computed in a fixed order -- the step kernels,
     // and the look-ahead schedule's replicated near parts, which run k_gemm with whole_tiles: one addition per target element.)
     if (const char* env = getenv("SF_LOOKAHEAD")) p->lookahead = atoi(env) != 0;      // 0: the round-1 schedule (tests cover both)
+    if (const char* env = getenv("SF_GRAPH")) p->use_graph = atoi(env) != 0;           // resident factorizations replayed as one hipGraph
     if (const char* env = getenv("SF_TOP_OWNER")) p->top_owner = atoi(env) != 0 && !lu;   // prototype schedule (Cholesky), see Segment::owner_gi
     if (const char* env = sf_exp_env("SF_LOOKAHEAD1")) p->lookahead1 = atoi(env) != 0 && nranks == 1 && !p->partial;
     if (const char* env = sf_exp_env("SF_LOOKAHEAD1_GRID")) p->la_grid = std::max(0, atoi(env));
@@ -1230,6 +1232,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if ((rc = up(&p->d_trsm, trsm))) break;
         if ((rc = up(&p->d_steps, steps))) break;
         {
+            p->n_flags = std::max<int32_t>(n_flags, 1);
             std::vector<int> zeros(std::max<int32_t>(n_flags, 1), 0);
             if ((rc = up(&p->d_flags, zeros))) break;
             const size_t tb = (size_t)std::max<int64_t>(max_diag_tasks, 1) * (lu ? 2048 : 1024) * sizeof(double);
@@ -1652,9 +1655,15 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); evs.push_back(e); }
     };
     if (first) {
-        HIP_TRY(hipEventRecord(p->ev0, st));
+        if (!p->capturing) HIP_TRY(hipEventRecord(p->ev0, st));
         p->packed_pending = -1;
         p->epoch = (p->epoch == 0x7fffffff) ? 1 : p->epoch + 1;     // flag value of this factorization's fused steps (never 0)
+        if (p->capturing) {
+            // a captured factorization is replayed with the SAME kernel arguments: its flag value is fixed (never seen in the array
+            // again: epochs only grow) and the flags are cleared by a node of the graph itself
+            p->graph_epoch = p->epoch;
+            HIP_TRY(hipMemsetAsync(p->d_flags, 0, (size_t)p->n_flags * sizeof(int), st));
+        }
     }
     sf::PivotCtl pc{0.0, 0.0, nullptr, nullptr, nullptr};
     if (p->lu) {
@@ -1750,7 +1759,7 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
         if (p->profiling) { kinds.push_back(L.kind); mark(); }
         if (p->dl_active) HIP_TRY(dl_publish(p, li + 1));
     }
-    if (last) HIP_TRY(hipEventRecord(p->ev1, st));
+    if (last && !p->capturing) HIP_TRY(hipEventRecord(p->ev1, st));
     HIP_TRY(hipGetLastError());
     if (p->profiling) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -2052,7 +2061,51 @@ int sf_chol_plan_set_stream(sf_chol_plan* p, void* stream) {
 }
 
 
-int sf_chol_plan_factorize(sf_chol_plan* p, int sync) { return sf_chol_plan_factorize_phase(p, -1, sync); }
+// SF_GRAPH=1: a whole resident factorization (memsets, assembly, every launch of the plan) is captured ONCE into a hipGraph and
+// replayed -- one submission instead of ~1,500 at 128^3.  Only the plain resident form: no overlapped download (its events are
+// recorded between the launches for host threads to wait on), no profiling, one rank, one lane.  The graph is rebuilt when a kernel
+// argument it froze changes (the LU pivot threshold / perturbation scale, the plan's stream).
+static int factorize_graph(sf_chol_plan* p, int sync) {
+    HIP_TRY(hipSetDevice(p->device));
+    const double eps = p->lu ? p->piv_perturb * p->amax : 0.0, tol = p->lu ? p->piv_tol : 0.0;
+    if (p->graph_exec && (p->graph_tol != tol || p->graph_eps != eps || p->graph_stream != p->stream)) {
+        (void)hipGraphExecDestroy(p->graph_exec);
+        p->graph_exec = nullptr;
+    }
+    bool fresh = false;
+    if (!p->graph_exec) {
+        fresh = true;
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+        p->capturing = true;
+        const int rc = run_launches(p, 0, p->launches.size(), true, true, 0);
+        p->capturing = false;
+        const hipError_t e = hipStreamEndCapture(p->stream, &g);
+        if (rc || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return rc ? rc : SF_ERR_HIP; }
+        const hipError_t ei = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) { p->graph_exec = nullptr; (void)hipGetLastError(); return SF_ERR_HIP; }
+        p->graph_tol = tol; p->graph_eps = eps; p->graph_stream = p->stream;
+    }
+    // (the captured kernels compare the flags with graph_epoch and the graph clears the flags itself; p->epoch stays what it is for
+    //  everybody else -- the generation of the factor on the device -- and moves on with every replay)
+    if (!fresh) p->epoch = (p->epoch == 0x7fffffff) ? 1 : p->epoch + 1;
+    p->packed_pending = -1;
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    return sync ? sf_chol_plan_sync(p) : SF_OK;
+}
+
+int sf_chol_plan_factorize(sf_chol_plan* p, int sync) {
+    if (p && !p->dry && p->values_set && p->use_graph && p->nranks == 1 && !p->partial && !p->dl_active && !p->profiling && !p->lookahead1) {
+        const int rc = factorize_graph(p, sync);
+        if (rc != SF_ERR_HIP) return rc;
+        p->use_graph = false;               // capture is not available here: the eager path from now on
+        (void)hipGetLastError();
+    }
+    return sf_chol_plan_factorize_phase(p, -1, sync);
+}
 
 // The whole of SparseFrame_validate on the device (C:3141-3266, L:3702-3858): b_i = 1 + i/n, the supernodal solve with the
 // resident factor, r = A x - b from the plan's copy of the matrix, residual = |r|_inf / (|A|_1 |x|_inf + |b|_inf).  Nothing

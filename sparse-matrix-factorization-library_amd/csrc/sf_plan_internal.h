@@ -183,6 +183,13 @@ struct sf_chol_plan {
     size_t launch_split = 0;    // launches [0, launch_split) belong to phase 0, the rest to phase 1
     // out-of-core plan (plan_create, ooc_group): number of streamed groups (0: in core), entries of one of the two group buffers,
     // pieces per group and how many of them are still on the device during a download
+    // SF_GRAPH=1 (sf_chol_plan_factorize): the resident factorization as one hipGraph
+    bool use_graph = false, capturing = false;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_epoch = 0;
+    int32_t n_flags = 1;
+    double graph_tol = 0, graph_eps = 0;
+    hipStream_t graph_stream = nullptr;
     bool factor_borrowed = false;       // d_Lsx is a buffer the creator lent (sf_plan_offer_factor_buffer): never freed here
     int ooc_groups = 0;
     int64_t ooc_buf = 0;

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from util import sf, gen, rel_err
+from util import sf, gen, rel_err, nd_perm_py
 
 pytestmark = pytest.mark.gpu
 
@@ -172,3 +172,44 @@ def test_more_handlers_than_work(monkeypatch, case):
     assert mi.validate() <= 1e-13
     mi.cleanup()
     common.close()
+
+
+def test_graph_replay_of_a_resident_factorization(oracle, monkeypatch):
+    """SF_GRAPH=1: the launches of a resident factorization captured once into a hipGraph and replayed (measured: no gain over the
+    eager launches, profiles/r04_ad_graph_replay.txt -- kept as an option, and kept correct): new values every time, an eager run
+    in between (profiling turns the graph off for that call), LU with a pivot perturbation whose scale changes with the values"""
+    monkeypatch.setenv("SF_GRAPH", "1")
+    N = 14
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(N, N, N), 1 << 30)
+    ref, info, _ = oracle.chol_factorize(S)
+    mask = oracle.lower_mask(S)
+    plan = sf.CholPlan(S)
+    for k, scale in enumerate((1.0, 4.0, 9.0, 16.0)):
+        plan.set_values(S.Lx * scale)
+        if k == 2:
+            plan.set_profiling(True)
+        plan.factorize()
+        if k == 2:
+            plan.set_profiling(False)
+        assert rel_err(plan.get_factor(), ref * np.sqrt(scale), mask) <= 1e-12
+        b = 1.0 + np.arange(n) / n
+        assert sf.validate_solution(S, plan.solve(b) * scale, b) <= 1e-12
+    plan.close()
+    import golden_large
+    c = golden_large.build_case("piv_zero_diag_12")
+    SL = c["sym"]
+    plan = sf.LUPlan(SL)
+    plan.set_pivoting(0.1)
+    for scale in (1.0, 3.0, 1.0):
+        plan.set_values(SL.Lx * scale, SL.Ux * scale)
+        plan.factorize()
+        want, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(SL, tol=0.1)
+        assert info == 0 and np.array_equal(plan.get_pivots(), pivpos)
+        got = plan.get_factor()
+        # L is scale-invariant, U scales: compare through the solve
+        b = 1.0 + np.arange(SL.n) / SL.n
+        x = plan.solve(b)
+        xr = oracle.lu_solve_pivot(SL, want, pivpos, b) / scale
+        assert np.max(np.abs(x - xr)) <= 1e-8 * np.max(np.abs(xr))
+    plan.close()
