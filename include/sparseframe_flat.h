@@ -157,22 +157,24 @@ int sf_chol_plan_top_region(sf_chol_plan *plan, void **device_ptr, sf_long *coun
  * `budget_entries` resident panel entries (doubles; LU stores two per entry): group[s] = streamed group of supernode s (whole
  * subtrees, consecutive in the postorder) or -1 = top.  The plan keeps the top panels resident and streams the groups through two
  * alternating buffers: group g is factorized while group g - 1 is copied to the host (device need = top + 2 x largest group;
- * *need_entries).  SF_OK: fits (ngroups == 1: in core); SF_ERR_ALLOC: no cut fits, group[] holds the cheapest one.
+ * *need_entries).  *top_mode (pass it on to the plan): 0 = all top panels resident, factorized after the last group; 1 = when
+ * that does not fit: a top panel only while it is ACTIVE (from the first group below it until its own factorization, right after
+ * the last one) -- *top_entries is then the arena the active panels share; slower, reaches factors of about three times the budget.  SF_OK: fits (ngroups == 1: in core); SF_ERR_ALLOC: no cut fits, group[] holds the cheapest one.
  * An out-of-core plan runs through sf_chol_plan_factorize_to_host only (the factor exists on the host, never as a whole on the
  * device): it refuses solve / validate / get_factor (SF_ERR_ARG).  SparseFrame_factorize picks this path by itself when the
  * in-core plan does not fit (SF_DEVICE_BUDGET_MB lowers the budget for tests). ---- */
 int sf_ooc_partition(sf_long nsuper, const sf_long *Super, const sf_long *SuperMap, const sf_long *Lsip, const sf_long *Lsi,
                      sf_long budget_entries, int32_t *group, int *ngroups, sf_long *group_entries, sf_long *top_entries,
-                     sf_long *need_entries);
+                     sf_long *need_entries, int *top_mode);
 int sf_chol_plan_create_ooc(sf_chol_plan **plan, int device, sf_long n, sf_long nsuper,
                             const sf_long *Super, const sf_long *SuperMap,
                             const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
-                            const sf_long *Lp, const sf_long *Li, const int32_t *group, int ngroups);
+                            const sf_long *Lp, const sf_long *Li, const int32_t *group, int ngroups, int top_mode);
 /* the same plan without a device (launch list, storage map, byte counts only; see sf_chol_plan_schedule_mapped) */
 int sf_chol_plan_schedule_ooc(sf_chol_plan **plan, sf_long n, sf_long nsuper,
                               const sf_long *Super, const sf_long *SuperMap,
                               const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
-                              const sf_long *Lp, const sf_long *Li, const int32_t *group, int ngroups);
+                              const sf_long *Lp, const sf_long *Li, const int32_t *group, int ngroups, int top_mode);
 
 /* ---- distributed top: the top supernodes' large GEMMs are SPLIT over the ranks instead of
  * replicated.  Every top panel is summed over the ranks exactly once, one 512-column block at a time, right before
@@ -317,7 +319,7 @@ int sf_lu_plan_create_ooc(sf_lu_plan **plan, int device, sf_long n, sf_long nsup
                           const sf_long *Super, const sf_long *SuperMap,
                           const sf_long *Lsip, const sf_long *Lsi, const sf_long *Lsxp,
                           const sf_long *Lp, const sf_long *Li, const sf_long *Up, const sf_long *Ui,
-                          const int32_t *group, int ngroups);
+                          const int32_t *group, int ngroups, int top_mode);
 int sf_lu_plan_set_values(sf_lu_plan *plan, const sf_float *Lx, const sf_float *Ux /* NULL if U aliases L */);
 /* Pivoting (BASELINE config 5 asks for it, the reference has none: magma_dgetrf_nopiv L:2653, devIpiv = NULL
  * L:3344, static pre-pivot L:589-673 disabled).  The symbolic structure is static, so rows can only be exchanged where that

@@ -127,13 +127,13 @@ lib.sf_subtree_partition.argtypes = [C.c_int64, c_long_p, c_long_p, c_long_p, c_
                                      c_double_p, c_double_p]
 lib.sf_subtree_partition.restype = C.c_int
 lib.sf_ooc_partition.argtypes = [C.c_int64, c_long_p, c_long_p, c_long_p, c_long_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int),
-                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
 lib.sf_ooc_partition.restype = C.c_int
-lib.sf_chol_plan_create_ooc.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7 + [C.POINTER(C.c_int32), C.c_int]
+lib.sf_chol_plan_create_ooc.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7 + [C.POINTER(C.c_int32), C.c_int, C.c_int]
 lib.sf_chol_plan_create_ooc.restype = C.c_int
-lib.sf_chol_plan_schedule_ooc.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64] + [c_long_p] * 7 + [C.POINTER(C.c_int32), C.c_int]
+lib.sf_chol_plan_schedule_ooc.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64] + [c_long_p] * 7 + [C.POINTER(C.c_int32), C.c_int, C.c_int]
 lib.sf_chol_plan_schedule_ooc.restype = C.c_int
-lib.sf_lu_plan_create_ooc.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9 + [C.POINTER(C.c_int32), C.c_int]
+lib.sf_lu_plan_create_ooc.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 9 + [C.POINTER(C.c_int32), C.c_int, C.c_int]
 lib.sf_lu_plan_create_ooc.restype = C.c_int
 lib.sf_chol_plan_create_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64] + [c_long_p] * 7 + [C.POINTER(C.c_int32), C.c_int]
 lib.sf_chol_plan_create_sharded.restype = C.c_int

@@ -167,18 +167,26 @@ def subtree_partition(sym, nranks, top_weight=1.0):
     return owner[:sym.nsuper], tf.value, ml.value
 
 
+class OocCut(tuple):
+    """(group, ngroups, largest group, top entries, need, fits) of ooc_partition, + .top_mode (0: top panels resident throughout,
+    1: only while active)"""
+    top_mode = 0
+
+
 def ooc_partition(sym, budget_entries):
-    """Out-of-core grouping (sf_ooc_partition): group[s] = streamed group of supernode s or -1 (resident top) for a budget of
+    """Out-of-core grouping (sf_ooc_partition): group[s] = streamed group of supernode s or -1 (top) for a budget of
     `budget_entries` resident panel entries.  Returns (group int32[nsuper], ngroups, entries of the largest group, top entries,
-    entries the cut needs, fits)."""
+    entries the cut needs, fits) with the attribute .top_mode to pass on to the plan."""
     group = np.zeros(max(sym.nsuper, 1), dtype=np.int32)
-    ng = C.c_int()
+    ng, mode = C.c_int(), C.c_int()
     ge, te, nd = C.c_int64(), C.c_int64(), C.c_int64()
     rc = lib.sf_ooc_partition(sym.nsuper, _lp(sym.Super), _lp(sym.SuperMap), _lp(sym.Lsip), _lp(sym.Lsi), int(budget_entries),
-                              group.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ng), C.byref(ge), C.byref(te), C.byref(nd))
+                              group.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ng), C.byref(ge), C.byref(te), C.byref(nd), C.byref(mode))
     if rc not in (0, 3):          # 3 = SF_ERR_ALLOC: no cut fits, the cheapest one is returned
         check(rc, "sf_ooc_partition")
-    return group[:sym.nsuper], ng.value, ge.value, te.value, nd.value, rc == 0
+    out = OocCut((group[:sym.nsuper], ng.value, ge.value, te.value, nd.value, rc == 0))
+    out.top_mode = mode.value
+    return out
 
 
 def top_groups(sym, owner):
@@ -335,14 +343,14 @@ class Schedule(_ScheduleMixin, _ShardedPlanMixin):
     """Rank `rank`'s plan of an nranks-way factorization WITHOUT a device (sf_chol_plan_schedule_mapped /
     sf_lu_plan_schedule_mapped): the launch list, segments, storage map and byte counts of the real plan, nothing allocated."""
 
-    def __init__(self, sym, owner, rank, nranks, lu=False, ooc_group=None, ooc_ngroups=0):
+    def __init__(self, sym, owner, rank, nranks, lu=False, ooc_group=None, ooc_ngroups=0, ooc_top_mode=0):
         """ooc_group / ooc_ngroups (owner None): the schedule of an out-of-core plan (sf_chol_plan_schedule_ooc)"""
         h = C.c_void_p()
         self._keep = [sym.Super, sym.SuperMap, sym.Lsip, sym.Lsi, sym.Lsxp, sym.Lp, sym.Li]
         if ooc_group is not None:
             grp = np.ascontiguousarray(ooc_group, dtype=np.int32)
             check(lib.sf_chol_plan_schedule_ooc(C.byref(h), sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
-                                                grp.ctypes.data_as(C.POINTER(C.c_int32)), int(ooc_ngroups)), "sf_chol_plan_schedule_ooc")
+                                                grp.ctypes.data_as(C.POINTER(C.c_int32)), int(ooc_ngroups), int(ooc_top_mode)), "sf_chol_plan_schedule_ooc")
             self._h, self.rank, self.nranks, self.nsuper = h, 0, 1, sym.nsuper
             return
         owner = np.ascontiguousarray(owner, dtype=np.int32)
@@ -386,7 +394,7 @@ class CholPlan(_ShardedPlanMixin, _ValidateMixin, _ScheduleMixin):
     rank/nranks (with phase): distributed top (sf_chol_plan_create_distributed), run with factorize_phase(0) and then
     factorize_segment(k) after summing segment_regions(k) over the ranks."""
 
-    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1, owner=None, ooc_group=None, ooc_ngroups=0):
+    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1, owner=None, ooc_group=None, ooc_ngroups=0, ooc_top_mode=0):
         """owner (with rank / nranks): the owner map of subtree_partition -> proportionally mapped plan
         (sf_chol_plan_create_mapped): own subtrees + the top supernodes above them, groups of ranks per top supernode.
         ooc_group / ooc_ngroups (from ooc_partition): out-of-core plan -- factorize_to_host only"""
@@ -395,7 +403,7 @@ class CholPlan(_ShardedPlanMixin, _ValidateMixin, _ScheduleMixin):
         if ooc_group is not None:
             grp = np.ascontiguousarray(ooc_group, dtype=np.int32)
             check(lib.sf_chol_plan_create_ooc(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
-                                              grp.ctypes.data_as(C.POINTER(C.c_int32)), int(ooc_ngroups)), "sf_chol_plan_create_ooc")
+                                              grp.ctypes.data_as(C.POINTER(C.c_int32)), int(ooc_ngroups), int(ooc_top_mode)), "sf_chol_plan_create_ooc")
         elif owner is not None:
             owner = np.ascontiguousarray(owner, dtype=np.int32)
             check(lib.sf_chol_plan_create_mapped(C.byref(h), device, sym.n, sym.nsuper, *[_lp(a) for a in self._keep],
@@ -471,7 +479,7 @@ class LUPlan(_ShardedPlanMixin, _ValidateMixin, _ScheduleMixin):
     """Device-resident supernodal no-pivot LU (flat ABI, sf_lu_plan_*).  `sym` comes from analyze(..., method='lu').
     phase/load_top/rank/nranks: distributed multi-GPU plan (sf_lu_plan_create_distributed), as CholPlan."""
 
-    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1, owner=None, ooc_group=None, ooc_ngroups=0):
+    def __init__(self, sym, device=0, phase=None, load_top=True, rank=0, nranks=1, owner=None, ooc_group=None, ooc_ngroups=0, ooc_top_mode=0):
         if not sym.lu:
             raise ValueError("LUPlan needs an LU symbolic analysis (method='lu')")
         h = C.c_void_p()
@@ -483,7 +491,7 @@ class LUPlan(_ShardedPlanMixin, _ValidateMixin, _ScheduleMixin):
         if ooc_group is not None:
             grp = np.ascontiguousarray(ooc_group, dtype=np.int32)
             check(lib.sf_lu_plan_create_ooc(C.byref(h), device, sym.n, sym.nsuper, *args,
-                                            grp.ctypes.data_as(C.POINTER(C.c_int32)), int(ooc_ngroups)), "sf_lu_plan_create_ooc")
+                                            grp.ctypes.data_as(C.POINTER(C.c_int32)), int(ooc_ngroups), int(ooc_top_mode)), "sf_lu_plan_create_ooc")
         elif owner is not None:
             owner = np.ascontiguousarray(owner, dtype=np.int32)
             check(lib.sf_lu_plan_create_mapped(C.byref(h), device, sym.n, sym.nsuper, *args,

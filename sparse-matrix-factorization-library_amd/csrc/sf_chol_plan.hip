@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "sf_plan_internal.h"
+#include "sf_symbolic.h"
 
 // hipEventElapsedTime whose failure (an event that was never recorded) is expected and must not stay behind as the thread's
 // "last error": callers that poll hipGetLastError after their own launches (PyTorch does) would report it as theirs
@@ -126,13 +127,16 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                        const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui,
                        const int32_t* phase_in = nullptr, int load_top = 1, int rank = 0, int nranks = 1,
                        const uint32_t* top_mask = nullptr, const double* root_cum = nullptr, bool dry = false,
-                       const int32_t* ooc_group = nullptr, int ooc_ngroups = 0) {
+                       const int32_t* ooc_group = nullptr, int ooc_ngroups = 0, int ooc_top_mode = 0) {
     // ooc_group (one device, nranks == 1, no phase array): OUT-OF-CORE plan -- the factor does not stay on the device.  ooc_group[s] in
     // [0, ooc_ngroups) = the streamed group of supernode s (sf::ooc_partition: whole subtrees, consecutive in the postorder), -1 = top.
     // The top panels are resident; the groups' panels alias TWO buffers of the largest group's size (group g lives in buffer g & 1)
     // and are factorized group by group, group g while group g - 1 is copied to the host; a group's buffer is zeroed and assembled
     // again (launch kind 7) once the copy of group g - 2 has left the device.  Such a plan only runs through the overlapped download
     // (sf_chol_plan_factorize_to_host); it cannot solve or hand out its factor (partial).
+    // ooc_top_mode 1 (sf::ooc_partition decides): the top panels are not resident throughout either -- a top supernode is assembled
+    // with the first group below it, factorized right after the last one, and its place in the top arena (sf::ooc_top_layout) is
+    // given to another two groups later.  For factors that mode 0's resident top does not fit.
     // dry: build the SCHEDULE only (launch list, segments, solve reduces, storage map, byte counts) -- no device is touched, nothing is
     // allocated or uploaded, and the resulting plan can only be inspected (sf_chol_plan_launch_info & co.) and destroyed.  It is the
     // same code path as a real plan up to the uploads, which is the point: what a rank WOULD do at a size or rank count this box cannot
@@ -219,11 +223,36 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         for (int g = 0; g < ooc_ngroups; ++g) run[(size_t)g] = (g & 1) * p->ooc_buf;
         int64_t top = 2 * p->ooc_buf;
         p->top_off = top;
-        for (sf_long s = 0; s < nsuper; ++s) {
-            int64_t& r = ooc_group[s] >= 0 ? run[(size_t)ooc_group[s]] : top;
-            XP[s] = r;
-            r += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
+        if (ooc_top_mode >= 1) {
+            p->ooc_first.assign((size_t)std::max<sf_long>(nsuper, 1), 0);
+            p->ooc_last.assign((size_t)std::max<sf_long>(nsuper, 1), 0);
+            std::vector<int64_t> toff((size_t)std::max<sf_long>(nsuper, 1), -1);
+            std::vector<int32_t> twait((size_t)std::max<sf_long>(nsuper, 1), -1);
+            int64_t arena = 0;
+            if (ooc_top_mode > 2 || sf::ooc_top_layout(nsuper, Super, SuperMap, Lsip, Lsi, ooc_group, ooc_ngroups, ooc_top_mode, p->ooc_first.data(),
+                                                       p->ooc_last.data(), toff.data(), twait.data(), &arena)) {
+                delete p;
+                return SF_ERR_ARG;
+            }
+            // the group whose copies have to be over before group g's first launch may write: g - 2 for its buffer, later ones for the
+            // places of the top panels that start with it (mode 2)
+            p->ooc_wait.assign((size_t)ooc_ngroups, -1);
+            for (int g = 0; g < ooc_ngroups; ++g) p->ooc_wait[(size_t)g] = g - 2;
+            for (sf_long s = 0; s < nsuper; ++s)
+                if (ooc_group[s] < 0) p->ooc_wait[(size_t)p->ooc_first[(size_t)s]] = std::max(p->ooc_wait[(size_t)p->ooc_first[(size_t)s]], twait[(size_t)s]);
+            for (sf_long s = 0; s < nsuper; ++s) {
+                if (ooc_group[s] >= 0) { int64_t& r = run[(size_t)ooc_group[s]]; XP[s] = r; r += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]); }
+                else XP[s] = top + toff[(size_t)s];
+            }
+            top += arena;
+        } else {
+            for (sf_long s = 0; s < nsuper; ++s) {
+                int64_t& r = ooc_group[s] >= 0 ? run[(size_t)ooc_group[s]] : top;
+                XP[s] = r;
+                r += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
+            }
         }
+        p->ooc_top_mode = ooc_top_mode >= 1 ? ooc_top_mode : 0;
         p->top_size = top - p->top_off;
         p->xC = top;
         XP[nsuper] = top;
@@ -442,15 +471,26 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 if ((int)bl.size() <= level[s]) bl.resize((size_t)level[s] + 1);
                 bl[(size_t)level[s]].push_back(s);
             }
-        for (int g = 0; g < ooc_ngroups; ++g)
+        std::vector<std::vector<std::vector<sf_long>>> top_gl((size_t)ooc_ngroups);      // mode 1: the top supernodes by (last group below, level)
+        if (ooc_top_mode >= 1)
+            for (sf_long s = 0; s < nsuper; ++s)
+                if (ooc_group[s] < 0) {
+                    auto& bl = top_gl[(size_t)p->ooc_last[(size_t)s]];
+                    if ((int)bl.size() <= level[s]) bl.resize((size_t)level[s] + 1);
+                    bl[(size_t)level[s]].push_back(s);
+                }
+        for (int g = 0; g < ooc_ngroups; ++g) {
             for (auto& v : by_gl[(size_t)g])
                 if (!v.empty()) { sets.push_back(LevelSet{0, std::move(v), 0, 0, 1}); sets.back().group = g; }
+            for (auto& v : top_gl[(size_t)g])
+                if (!v.empty()) sets.push_back(LevelSet{1, std::move(v), all_ranks, 0, 1});
+        }
         // (Measured and not kept: every top supernode right after the last group below it -- the lower separators factorized and
         // on their way to the host while later groups still stream.  128^3 with 8 groups: 0.69 s against 0.60 s with the top at the end:
         // a top supernode then runs alone instead of with its level, and it delays the next group, whose download is what the
         // group phase is bound by.)
     }
-    for (int ph = ooc ? 1 : 0; ph < 2; ++ph) {
+    for (int ph = ooc ? 1 : 0; ph < 2 && !(ooc && ooc_top_mode >= 1); ++ph) {
         std::vector<std::vector<sf_long>> by_level(nlevels);
         for (sf_long s = 0; s < nsuper; ++s)
             if (p->phase[s] == ph) by_level[level[s]].push_back(s);
@@ -1135,7 +1175,7 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
             p->dl_group_pieces.assign((size_t)ooc_ngroups, 0);
             for (DlPiece& pc : p->dl_pieces) {
                 const sf_long s = (sf_long)(std::upper_bound(Lsxp, Lsxp + nsuper + 1, (sf_long)pc.host_off) - Lsxp) - 1;
-                pc.group = (s >= 0 && s < nsuper) ? ooc_group[s] : -1;
+                pc.group = (s >= 0 && s < nsuper) ? (ooc_group[s] >= 0 ? ooc_group[s] : (ooc_top_mode >= 1 ? p->ooc_last[(size_t)s] : -1)) : -1;
                 if (pc.group >= 0) ++p->dl_group_pieces[(size_t)pc.group];
             }
         }
@@ -1316,9 +1356,21 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
         if (ooc) {
             // one assembly mask per group, then the top's: d_loadmask + g * nsuper (g = ooc_ngroups: the top)
             std::vector<int8_t> mask((size_t)(ooc_ngroups + 1) * (size_t)std::max<sf_long>(nsuper, 1), 0);
-            for (sf_long s = 0; s < nsuper; ++s)
-                mask[(size_t)(ooc_group[s] >= 0 ? ooc_group[s] : ooc_ngroups) * (size_t)nsuper + (size_t)s] = 1;
+            for (sf_long s = 0; s < nsuper; ++s) {
+                const int unit = ooc_group[s] >= 0 ? ooc_group[s] : (ooc_top_mode >= 1 ? p->ooc_first[(size_t)s] : ooc_ngroups);
+                mask[(size_t)unit * (size_t)nsuper + (size_t)s] = 1;
+            }
             if ((rc = up(&p->d_loadmask, mask))) break;
+            if (ooc_top_mode >= 1) {        // what a group's first launch zeroes besides its buffer: the places of the top panels that start with it
+                p->ooc_zero.assign((size_t)ooc_ngroups, {});
+                for (sf_long s = 0; s < nsuper; ++s)
+                    if (ooc_group[s] < 0) {
+                        auto& z = p->ooc_zero[(size_t)p->ooc_first[(size_t)s]];
+                        const int64_t o = XP[s], len = (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
+                        if (!z.empty() && z.back().first + z.back().second == o) z.back().second += len;
+                        else z.push_back({o, len});
+                    }
+            }
         } else if (p->partial) {
             std::vector<int8_t> mask(std::max<sf_long>(nsuper, 1), 0);
             // the matrix entries of a shared top panel enter the sum once: on the first rank of its group (load_top == 2),
@@ -1386,29 +1438,29 @@ int sf_chol_plan_create_sharded(sf_chol_plan** out, int device, sf_long n, sf_lo
 int sf_chol_plan_create_ooc(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
                             const sf_long* Super, const sf_long* SuperMap,
                             const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
-                            const sf_long* Lp, const sf_long* Li, const int32_t* group, int ngroups) {
+                            const sf_long* Lp, const sf_long* Li, const int32_t* group, int ngroups, int top_mode) {
     if (ngroups > 1 && !group) return SF_ERR_ARG;
     return plan_create(out, device, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, nullptr, 1, 0, 1,
-                       nullptr, nullptr, false, group, ngroups);
+                       nullptr, nullptr, false, group, ngroups, top_mode);
 }
 
 // schedule-only out-of-core plan (no device; see sf_chol_plan_schedule_mapped): what the launch list and the storage would be
 int sf_chol_plan_schedule_ooc(sf_chol_plan** out, sf_long n, sf_long nsuper,
                               const sf_long* Super, const sf_long* SuperMap,
                               const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
-                              const sf_long* Lp, const sf_long* Li, const int32_t* group, int ngroups) {
+                              const sf_long* Lp, const sf_long* Li, const int32_t* group, int ngroups, int top_mode) {
     if (ngroups > 1 && !group) return SF_ERR_ARG;
     return plan_create(out, 0, false, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, nullptr, nullptr, nullptr, 1, 0, 1,
-                       nullptr, nullptr, true, group, ngroups);
+                       nullptr, nullptr, true, group, ngroups, top_mode);
 }
 
 int sf_lu_plan_create_ooc(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
                           const sf_long* Super, const sf_long* SuperMap,
                           const sf_long* Lsip, const sf_long* Lsi, const sf_long* Lsxp,
-                          const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui, const int32_t* group, int ngroups) {
+                          const sf_long* Lp, const sf_long* Li, const sf_long* Up, const sf_long* Ui, const int32_t* group, int ngroups, int top_mode) {
     if (ngroups > 1 && !group) return SF_ERR_ARG;
     return plan_create(out, device, true, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, nullptr, 1, 0, 1,
-                       nullptr, nullptr, false, group, ngroups);
+                       nullptr, nullptr, false, group, ngroups, top_mode);
 }
 
 int sf_chol_plan_create_distributed(sf_chol_plan** out, int device, sf_long n, sf_long nsuper,
@@ -1717,11 +1769,13 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
             case 1: sf::launch_trsm(p->d_trsm + L.first, L.count, p->d_Lsx, pc.pivinv, st); break;
             case 7: {       // out of core: group L.first takes over buffer L.first & 1
                 const int g = (int)L.first;
-                if (g >= 2) {
-                    // ... once every piece of group g - 2 has LEFT the device (its DMA into the pinned ring is complete; the copy
-                    // workers count).  Everything group g - 2's pieces wait for has been enqueued and published by now.
+                // ... once every piece of group g - 2 has LEFT the device (its DMA into the pinned ring is complete; the copy workers
+                // count) -- with top mode 2 possibly of a later group, whose top panels' places are taken over here.  Everything those
+                // pieces wait for has been enqueued and published by now.
+                const int upto = p->ooc_wait.empty() ? g - 2 : p->ooc_wait[(size_t)g];
+                for (int w = std::max(0, g - 2); w <= upto && w < g; ++w) {
                     std::unique_lock<std::mutex> lk(p->dl_mu);
-                    p->dl_cv.wait(lk, [&] { return p->dl_abort || p->dl_group_left[(size_t)(g - 2)].load() <= 0; });
+                    p->dl_cv.wait(lk, [&] { return p->dl_abort || p->dl_group_left[(size_t)w].load() <= 0; });
                     if (p->dl_abort) return SF_ERR_HIP;
                 }
                 if (g >= 2 && p->ooc_buf > 0) {      // (the first factorization step zeroed everything: groups 0 and 1 find clean buffers)
@@ -1729,6 +1783,11 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
                     HIP_TRY(hipMemsetAsync(p->d_Lsx + off, 0, nb, st));
                     if (p->lu) HIP_TRY(hipMemsetAsync(p->d_Lsx + p->xC + off, 0, nb, st));
                 }
+                if (p->ooc_top_mode >= 1)       // the top panels that become active with this group (their places may have held others)
+                    for (const auto& z : p->ooc_zero[(size_t)g]) {
+                        HIP_TRY(hipMemsetAsync(p->d_Lsx + z.first, 0, (size_t)z.second * sizeof(double), st));
+                        if (p->lu) HIP_TRY(hipMemsetAsync(p->d_Lsx + p->xC + z.first, 0, (size_t)z.second * sizeof(double), st));
+                    }
                 assemble(p->d_loadmask + (size_t)g * (size_t)p->nsuper, st);
                 break;
             }

@@ -475,7 +475,7 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
         // top panels resident, subtree groups streamed through two buffers while the finished ones travel to Lsx_out -- the role the
         // reference gives its slot-sized stages (C:1721-1846, C:2421-2467).  Decided here, per pattern, before the plan is built.
         std::vector<int32_t> ooc_group;
-        int ooc_ngroups = 1;
+        int ooc_ngroups = 1, ooc_mode = 0;
         auto plan_ooc = [&](double shrink) -> int {
             int64_t entries = 0;
             for (sf_long s = 0; s < nsuper; ++s) entries += (Super[s + 1] - Super[s]) * (Lsip[s + 1] - Lsip[s]);
@@ -498,11 +498,11 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
             if (budget_entries <= 0) return SF_ERR_ALLOC;
             ooc_group.assign((size_t)std::max<sf_long>(nsuper, 1), 0);
             int64_t ge = 0, te = 0, nd = 0;
-            const int rc = sf::ooc_partition(nsuper, Super, SuperMap, Lsip, Lsi, budget_entries, ooc_group.data(), &ooc_ngroups, &ge, &te, &nd);
+            const int rc = sf::ooc_partition(nsuper, Super, SuperMap, Lsip, Lsi, budget_entries, ooc_group.data(), &ooc_ngroups, &ge, &te, &nd, &ooc_mode);
             if (trace || rc)
                 fprintf(stderr, "[sparseframe-hip] factorize: %.2f GB of panels against a device budget of %.2f GB -> out of core: %d groups, "
-                                "top %.2f GB resident + 2 buffers of %.2f GB%s\n", entries * per_entry / 1e9, budget / 1e9, ooc_ngroups,
-                        te * per_entry / 1e9, ge * per_entry / 1e9, rc == 2 ? " -- DOES NOT FIT" : "");
+                                "top %.2f GB %s + 2 buffers of %.2f GB%s\n", entries * per_entry / 1e9, budget / 1e9, ooc_ngroups,
+                        te * per_entry / 1e9, ooc_mode == 1 ? "for the active top panels" : "resident", ge * per_entry / 1e9, rc == 2 ? " -- DOES NOT FIT" : "");
             return rc == 0 ? SF_OK : (rc == 2 ? SF_ERR_ALLOC : SF_ERR_ARG);
         };
         auto create = [&]() {
@@ -513,8 +513,8 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
                 ~Claim() { sf_plan_offer_factor_buffer(nullptr, 0); if (offered && plan && sf_plan_factor_borrowed(plan)) S.pool_user = plan; }
             } claim{S, plan, offered};
             if (ooc_ngroups > 1)
-                return lu ? sf_lu_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, ooc_group.data(), ooc_ngroups)
-                          : sf_chol_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, ooc_group.data(), ooc_ngroups);
+                return lu ? sf_lu_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui, ooc_group.data(), ooc_ngroups, ooc_mode)
+                          : sf_chol_plan_create_ooc(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, ooc_group.data(), ooc_ngroups, ooc_mode);
             return lu ? sf_lu_plan_create(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li, Up, Ui)
                       : sf_chol_plan_create(&plan, H.gpuIndex_physical, n, nsuper, Super, SuperMap, Lsip, Lsi, Lsxp, Lp, Li);
         };

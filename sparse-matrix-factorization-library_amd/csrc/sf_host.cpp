@@ -212,13 +212,16 @@ int sf_subtree_partition_weighted(sf_long nsuper, const sf_long* Super, const sf
 }
 
 int sf_ooc_partition(sf_long nsuper, const sf_long* Super, const sf_long* SuperMap, const sf_long* Lsip, const sf_long* Lsi,
-                     sf_long budget_entries, int32_t* group, int* ngroups, sf_long* group_entries, sf_long* top_entries, sf_long* need_entries) {
+                     sf_long budget_entries, int32_t* group, int* ngroups, sf_long* group_entries, sf_long* top_entries, sf_long* need_entries,
+                     int* top_mode) {
     if (!Super || !Lsip || !group || !ngroups || (nsuper > 0 && (!SuperMap || !Lsi))) return SF_ERR_ARG;
     int64_t ge = 0, te = 0, nd = 0;
-    const int rc = sf::ooc_partition(nsuper, Super, SuperMap, Lsip, Lsi, budget_entries, group, ngroups, &ge, &te, &nd);
+    int mode = 0;
+    const int rc = sf::ooc_partition(nsuper, Super, SuperMap, Lsip, Lsi, budget_entries, group, ngroups, &ge, &te, &nd, &mode);
     if (group_entries) *group_entries = ge;
     if (top_entries) *top_entries = te;
     if (need_entries) *need_entries = nd;
+    if (top_mode) *top_mode = mode;
     return rc == 0 ? SF_OK : (rc == 2 ? SF_ERR_ALLOC : SF_ERR_ARG);
 }
 

@@ -193,6 +193,11 @@ struct sf_chol_plan {
     bool factor_borrowed = false;       // d_Lsx is a buffer the creator lent (sf_plan_offer_factor_buffer): never freed here
     int ooc_groups = 0;
     int64_t ooc_buf = 0;
+    // top mode 1 (active top panels only): first / last group below every top supernode, and per group the (offset, length) ranges its
+    // first launch zeroes for the top panels that start with it
+    int ooc_top_mode = 0;
+    std::vector<int32_t> ooc_first, ooc_last, ooc_wait;     // ooc_wait[g]: the last group whose copies group g's first launch waits for
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> ooc_zero;
     std::vector<int64_t> dl_group_pieces;
     std::unique_ptr<std::atomic<int64_t>[]> dl_group_left;
     int rank = 0, nranks = 1;   // distributed top: this rank's share of the split launches

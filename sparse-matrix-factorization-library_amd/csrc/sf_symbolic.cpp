@@ -1018,78 +1018,173 @@ int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, cons
 // Grouping for a factor that does not fit the device (the reference's answer to the same question is its slot-sized "stages"
 // streamed through the device, C:1721-1846 / C:2421-2467).  The supernodal tree is cut at a size S: every maximal
 // subtree of at most S panel entries is a unit, consecutive units (postorder) are packed into GROUPS of at most S entries, every
-// supernode above the cut is "top".  The numeric phase keeps the top panels resident for the whole factorization (they receive
-// the Schur updates of everything below them) and streams the groups through two alternating buffers of S entries: group g is
-// factorized while group g - 1 travels to the host.  Device need = top + 2 S (one group: top = 0, S = everything: in core).
-// The cut is the LARGEST S of a geometric ladder that fits `budget` entries -- fewest groups, smallest top.
-// group[s] in [0, *ngroups) or -1 (top).  Returns 0; 2 when no cut of the ladder fits (group[] then holds the cheapest one and
-// *need says what it would take).
+// supernode above the cut is "top".  The groups stream through two alternating buffers of S entries: group g is factorized while
+// group g - 1 travels to the host.  The top panels receive the Schur updates of everything below them and are
+//   mode 0  resident for the whole factorization, factorized after the last group (device need = all top panels + 2 S), or
+//   mode 1  resident only while they are ACTIVE: a top supernode is allocated when the first group below it starts, factorized
+//           right after the last one, and its space is used again two groups later (by then its copy has left the device):
+//           need = the largest set of simultaneously active top panels (laid out first-fit by ooc_top_layout) + 2 S.  Slower --
+//           a top supernode no longer shares launches with its whole level -- so it is only chosen when mode 0 does not fit;
+//   mode 2  as mode 1 with the space used again ONE group later: the device then waits for the copy of the panel that was there
+//           (the only mode with such waits), need = the active path of top panels + 2 S.
+// The cut is the LARGEST S of a geometric ladder that fits `budget` entries, mode 0 before mode 1 before mode 2.
+// group[s] in [0, *ngroups) or -1 (top).  Returns 0; 2 when nothing fits (group[] then holds the cheapest cut, *need what it takes).
 // ---------------------------------------------------------------------------------------------
-int ooc_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, int64_t budget,
-                  int32_t* group, int* ngroups, int64_t* group_entries, int64_t* top_entries, int64_t* need) {
-    if (nsuper < 0 || !group || !ngroups || (nsuper > 0 && (!Super || !SuperMap || !Lsip || !Lsi))) return 1;
-    std::vector<Long> par((size_t)nsuper, -1);
-    std::vector<int64_t> sz((size_t)nsuper, 0), sub((size_t)nsuper, 0);
+namespace {
+struct OocTree {
+    std::vector<Long> par;
+    std::vector<int64_t> sz, sub;
     int64_t total = 0;
+};
+int ooc_tree(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, OocTree& T) {
+    T.par.assign((size_t)nsuper, -1);
+    T.sz.assign((size_t)nsuper, 0);
+    T.sub.assign((size_t)nsuper, 0);
+    T.total = 0;
     for (Long s = 0; s < nsuper; ++s) {
         const Long nscol = Super[s + 1] - Super[s], nsrow = Lsip[s + 1] - Lsip[s];
-        sz[s] = (int64_t)nscol * nsrow;
-        total += sz[s];
+        T.sz[s] = (int64_t)nscol * nsrow;
+        T.total += T.sz[s];
         if (nscol < nsrow) {
-            par[s] = SuperMap[Lsi[Lsip[s] + nscol]];
-            if (par[s] <= s || par[s] >= nsuper) return 1;      // postordered
+            T.par[s] = SuperMap[Lsi[Lsip[s] + nscol]];
+            if (T.par[s] <= s || T.par[s] >= nsuper) return 1;      // postordered
         }
     }
     for (Long s = 0; s < nsuper; ++s) {
-        sub[s] += sz[s];
-        if (par[s] >= 0) sub[par[s]] += sub[s];
+        T.sub[s] += T.sz[s];
+        if (T.par[s] >= 0) T.sub[T.par[s]] += T.sub[s];
     }
+    return 0;
+}
+}  // namespace
+
+// Mode 1 / 2 layout of the top panels of a grouping (mode 2: a place is given to the next panel ONE group after its panel's last
+// group instead of two -- the copy of the old panel may then still be on its way and the new one's first launch waits for it:
+// wait[s] = the group whose copies must be over first): first[s] / last[s] = the first and the last group below top supernode s (a top
+// supernode without grouped descendants: the group before it), off[s] = its offset in the top arena (-1 for grouped supernodes),
+// *arena = the arena's size.  A panel is live from the start of group first[s] until two groups after last[s]; panels whose lives
+// overlap never share addresses (first fit, ancestors before descendants).
+int ooc_top_layout(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, const int32_t* group, int ngroups,
+                   int mode, int32_t* first, int32_t* last, int64_t* off, int32_t* wait, int64_t* arena) {
+    if (nsuper < 0 || !group || ngroups < 1 || !first || !last || !off || !arena || (mode != 1 && mode != 2)) return 1;
+    const int lag = mode == 1 ? 2 : 1;          // a place is free again `lag` groups after its panel's last group
+    OocTree T;
+    if (ooc_tree(nsuper, Super, SuperMap, Lsip, Lsi, T)) return 1;
+    int32_t prev = 0;
+    for (Long s = 0; s < nsuper; ++s) { first[s] = INT32_MAX; last[s] = -1; off[s] = -1; if (wait) wait[s] = -1; }
+    for (Long s = 0; s < nsuper; ++s) {
+        if (group[s] >= 0) { first[s] = last[s] = group[s]; prev = group[s]; }
+        else if (last[s] < 0) first[s] = last[s] = prev;
+        if (T.par[s] >= 0) {
+            const Long p = T.par[s];
+            first[p] = std::min(first[p], first[s]);
+            last[p] = std::max(last[p], last[s]);
+        }
+    }
+    // by unit: release what ended two groups ago, then place what starts now -- the larger index (the ancestor, which lives longest) first
+    std::vector<std::vector<Long>> starts((size_t)ngroups);
+    for (Long s = nsuper - 1; s >= 0; --s)
+        if (group[s] < 0) starts[(size_t)first[s]].push_back(s);
+    struct Live { int64_t off, size; int32_t until; };
+    std::vector<Live> live, gone;       // live: sorted by offset; gone: every place that was given back, with the group its panel ended with
+    int64_t top = 0;
+    for (int u = 0; u < ngroups; ++u) {
+        for (const Live& L : live)
+            if (L.until + lag <= u) gone.push_back(L);
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& L) { return L.until + lag <= u; }), live.end());
+        for (Long s : starts[(size_t)u]) {
+            const int64_t size = T.sz[s];
+            int64_t at = 0;
+            size_t pos = 0;
+            for (; pos < live.size(); ++pos) {
+                if (live[pos].off - at >= size) break;
+                at = live[pos].off + live[pos].size;
+            }
+            live.insert(live.begin() + (std::ptrdiff_t)pos, Live{at, size, last[s]});
+            off[s] = at;
+            top = std::max(top, at + size);
+            if (wait) {         // the latest group whose copy to the host has to be over before this place may be written again
+                int32_t w = -1;
+                for (const Live& G : gone)
+                    if (G.off < at + size && at < G.off + G.size) w = std::max(w, G.until);
+                wait[s] = w;
+            }
+        }
+    }
+    *arena = top;
+    return 0;
+}
+
+int ooc_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, int64_t budget,
+                  int32_t* group, int* ngroups, int64_t* group_entries, int64_t* top_entries, int64_t* need, int* top_mode) {
+    if (nsuper < 0 || !group || !ngroups || (nsuper > 0 && (!Super || !SuperMap || !Lsip || !Lsi))) return 1;
+    OocTree T;
+    if (ooc_tree(nsuper, Super, SuperMap, Lsip, Lsi, T)) return 1;
+    const std::vector<Long>& par = T.par;
+    const std::vector<int64_t>& sz = T.sz;
+    const std::vector<int64_t>& sub = T.sub;
+    const int64_t total = T.total;
     constexpr int MAX_GROUPS = 4096;
-    // the cut at S: out = groups (nullptr: only count); returns top + (2 or 1) * largest group
-    auto cut = [&](int64_t S, int32_t* out, int* ng, int64_t* gmax, int64_t* top) {
+    std::vector<int32_t> f((size_t)std::max<Long>(nsuper, 1)), l((size_t)std::max<Long>(nsuper, 1));
+    std::vector<int64_t> o((size_t)std::max<Long>(nsuper, 1));
+    // the cut at S: returns the entries that have to be resident; mode 1: the top's share of that is the arena of ooc_top_layout
+    auto cut = [&](int64_t S, int mode, int32_t* out, int* ng, int64_t* gmax, int64_t* top) -> int64_t {
         int64_t t = 0, cur = 0, mx = 0;
         int g = 0;
         bool open = false;
+        Long prev_top = -2;
         for (Long s = 0; s < nsuper; ++s) {
-            if (sub[s] > S) { t += sz[s]; if (out) out[s] = -1; continue; }
+            if (sub[s] > S) { t += sz[s]; out[s] = -1; continue; }
             const bool unit_root = par[s] < 0 || sub[par[s]] > S;
             if (!unit_root) continue;
             // the unit = supernodes (s - its descendants .. s]: a contiguous range of the postorder that ends at s
-            if (open && cur + sub[s] > S) { ++g; cur = 0; }
+            // (modes 1 / 2: a group never holds subtrees of two different top supernodes -- the lives of sibling top panels would
+            // overlap in that group and the arena would have to hold both)
+            const bool other_parent = mode >= 1 && open && par[s] != prev_top;
+            if (open && (cur + sub[s] > S || other_parent)) { ++g; cur = 0; }
+            prev_top = par[s];
             open = true;
             cur += sub[s];
             mx = std::max(mx, cur);
-            if (out) out[s] = g;
+            out[s] = g;
         }
-        if (out)        // descendants take their unit root's group (parents come later in the postorder: walk down)
-            for (Long s = nsuper - 1; s >= 0; --s)
-                if (sub[s] <= S && par[s] >= 0 && sub[par[s]] <= S) out[s] = out[par[s]];
+        // descendants take their unit root's group (parents come later in the postorder: walk down)
+        for (Long s = nsuper - 1; s >= 0; --s)
+            if (sub[s] <= S && par[s] >= 0 && sub[par[s]] <= S) out[s] = out[par[s]];
         const int n_g = open ? g + 1 : 0;
+        if (mode >= 1 && n_g > 1 && n_g <= MAX_GROUPS) {
+            int64_t arena = 0;
+            if (ooc_top_layout(nsuper, Super, SuperMap, Lsip, Lsi, out, n_g, mode, f.data(), l.data(), o.data(), nullptr, &arena) == 0) t = arena;
+        }
         if (ng) *ng = n_g;
         if (gmax) *gmax = mx;
         if (top) *top = t;
         return t + (n_g > 1 ? 2 : 1) * mx;
     };
     int64_t bestS = total, best_need = total;       // everything in one group: in core
+    int best_mode = 0;
     bool fits = total <= budget;
     if (!fits) {
         best_need = INT64_MAX;
-        double S = (double)budget / 2.0;
-        for (int it = 0; it < 96 && S >= 1.0; ++it, S *= 0.85) {
-            int ng = 0;
-            const int64_t nd = cut((int64_t)S, nullptr, &ng, nullptr, nullptr);
-            if (ng > MAX_GROUPS) break;
-            if (nd < best_need) { best_need = nd; bestS = (int64_t)S; }
-            if (nd <= budget) { best_need = nd; bestS = (int64_t)S; fits = true; break; }
+        for (int mode = 0; mode < 3 && !fits; ++mode) {
+            double S = (double)budget / 2.0;
+            for (int it = 0; it < 96 && S >= 1.0; ++it, S *= 0.85) {
+                int ng = 0;
+                const int64_t nd = cut((int64_t)S, mode, group, &ng, nullptr, nullptr);
+                if (ng > MAX_GROUPS) break;
+                if (nd < best_need) { best_need = nd; bestS = (int64_t)S; best_mode = mode; }
+                if (nd <= budget) { fits = true; break; }
+            }
         }
     }
     int ng = 0;
     int64_t gmax = 0, top = 0;
-    const int64_t nd = cut(bestS, group, &ng, &gmax, &top);
+    const int64_t nd = cut(bestS, best_mode, group, &ng, &gmax, &top);
     *ngroups = ng;
     if (group_entries) *group_entries = gmax;
     if (top_entries) *top_entries = top;
     if (need) *need = nd;
+    if (top_mode) *top_mode = (ng > 1) ? best_mode : 0;
     return fits ? 0 : 2;
 }
 

@@ -91,9 +91,12 @@ double flops_exec(const Symbolic& S, double* update_flops, double* scatter_elems
 int subtree_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi,
                       int nranks, int32_t* owner, double* top_fraction, double* max_load_fraction, double top_weight = 1.0);
 
-// out-of-core grouping (sf_symbolic.cpp): group[s] = streamed group of supernode s or -1 (resident top); 0 = fits `budget` panel entries
+// out-of-core grouping (sf_symbolic.cpp): group[s] = streamed group of supernode s or -1 (top); *top_mode 0 = the top panels are
+// resident throughout, 1 / 2 = only while active (ooc_top_layout gives their offsets; 2: places re-used one group earlier); 0 = fits `budget` panel entries
 int ooc_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, int64_t budget,
-                  int32_t* group, int* ngroups, int64_t* group_entries, int64_t* top_entries, int64_t* need);
+                  int32_t* group, int* ngroups, int64_t* group_entries, int64_t* top_entries, int64_t* need, int* top_mode);
+int ooc_top_layout(Long nsuper, const Long* Super, const Long* SuperMap, const Long* Lsip, const Long* Lsi, const int32_t* group, int ngroups,
+                   int mode, int32_t* first, int32_t* last, int64_t* off, int32_t* wait, int64_t* arena);
 
 int graph_nd_perm(Long n, const Long* Cp, const Long* Ci, Long leaf, Long* perm);
 

@@ -57,11 +57,13 @@ def test_grouping_properties(case):
     assert fits and ng == 1 and te == 0 and nd == total and (g == 0).all()
     seen_cut = False
     for frac in (0.9, 0.75, 0.6, 0.45, 0.3):
-        g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * frac))
+        cut = sf.ooc_partition(S, int(total * frac))
+        g, ng, ge, te, nd, fits = cut
         assert ng >= 2
         seen_cut = True
         top = g < 0
-        assert int(ent[top].sum()) == te
+        # (top mode 0: every top panel resident; 1 / 2 -- only chosen when that does not fit: the arena of the active ones)
+        assert int(ent[top].sum()) == te if cut.top_mode == 0 else te <= int(ent[top].sum())
         sizes = np.bincount(g[~top], weights=ent[~top], minlength=ng).astype(np.int64)
         assert sizes.max() == ge and nd == te + 2 * ge
         assert (not fits) or nd <= int(total * frac)
@@ -141,6 +143,90 @@ def test_out_of_core_cholesky_matches_the_oracle(oracle, case, frac):
         plan.solve(np.ones(n))
     with pytest.raises(sf.SparseFrameError, match="SF_ERR_ARG"):
         plan.get_factor()
+    plan.close()
+
+
+def test_active_top_layout_never_shares_a_place_between_two_live_panels():
+    """top modes 1 / 2 (schedule-only plans): two top panels whose places in the arena overlap are never active at the same time --
+    mode 1: the second one starts at least two groups after the first one's last group, mode 2: at least one; the arena is what the
+    partition promised and, in mode 2, no larger than the largest set of simultaneously active panels would need with perfect packing
+    x 1.5; every group's first launch comes before the launches of the top supernodes that start with it"""
+    N = 24
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(N, N, N), 1 << 30)
+    ent, par = panel_entries(S), parents(S)
+    total = int(ent.sum())
+    cuts = {}
+    for frac in np.arange(0.60, 0.30, -0.01):         # the first budget at which each mode is the partition's answer
+        cut = sf.ooc_partition(S, int(total * frac))
+        if cut[5] and cut.top_mode not in cuts:
+            cuts[cut.top_mode] = cut
+    assert set(cuts) == {0, 1, 2}, sorted(cuts)
+    for want_mode in (1, 2):
+        cut = cuts[want_mode]
+        g, ng, ge, te, nd, fits = cut
+        ns = int(S.nsuper)
+        first, last, prev = np.full(ns, 10 ** 9), np.full(ns, -1), 0
+        for s in range(ns):
+            if g[s] >= 0:
+                first[s] = last[s] = prev = g[s]
+            elif last[s] < 0:
+                first[s] = last[s] = prev
+            if par[s] >= 0:
+                first[par[s]], last[par[s]] = min(first[par[s]], first[s]), max(last[par[s]], last[s])
+        sch = sf.Schedule(S, None, 0, 1, ooc_group=g, ooc_ngroups=ng, ooc_top_mode=cut.top_mode)
+        xp = sch.panel_offsets(S.nsuper)
+        tops = np.nonzero(g < 0)[0]
+        lag = 2 if cut.top_mode == 1 else 1
+        assert (xp[tops] >= 2 * ge).all() and int((xp[tops] + ent[tops]).max()) - 2 * ge == te
+        for i, a in enumerate(tops):
+            for b in tops[i + 1:]:
+                if xp[a] < xp[b] + ent[b] and xp[b] < xp[a] + ent[a]:
+                    assert first[b] >= last[a] + lag or first[a] >= last[b] + lag, (a, b)
+        active = max(int(ent[tops][(first[tops] <= u) & (last[tops] + lag - 1 >= u)].sum()) for u in range(ng))
+        assert active <= te <= 1.5 * active
+        sch.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("case", chol_cases(), ids=lambda c: c[0])
+def test_active_top_modes_match_the_oracle(oracle, case, mode, monkeypatch):
+    """top panels resident only while active (mode 1), with their places re-used one group later and the waits that takes (mode 2):
+    same factor; small staging slots so that every group and every top run has several pieces"""
+    monkeypatch.setenv("SF_DL_SLOT_MB", "1")
+    name, n, Cp, Ci, Cx, perm, slot = case
+    S = sf.analyze(n, Cp, Ci, Cx, perm, slot)
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.25))        # a fine cut (whatever mode it reports)
+    assert ng >= 3
+    plan = sf.CholPlan(S, ooc_group=g, ooc_ngroups=ng, ooc_top_mode=mode)
+    ref, info, _ = oracle.chol_factorize(S)
+    mask = oracle.lower_mask(S)
+    for rep in range(2):
+        out = np.full(S.xsize, np.nan)
+        plan.factorize_to_host(S.Lx, out=out)
+        assert not np.isnan(out[mask]).any()
+        assert rel_err(out, ref, mask) <= TOL_FACTOR
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_active_top_modes_lu_with_interchanges(oracle, mode):
+    import golden_large
+    c = golden_large.build_case("piv_zero_diag_12")
+    n, S = c["n"], c["sym"]
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.3))
+    assert ng >= 3
+    plan = sf.LUPlan(S, ooc_group=g, ooc_ngroups=ng, ooc_top_mode=mode)
+    plan.set_pivoting(0.1)
+    out = np.full(S.xsize, np.nan)
+    plan.factorize_to_host(S.Lx, S.Ux, out=out)
+    ref, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=0.1)
+    assert info == 0 and np.array_equal(plan.get_pivots(), pivpos)
+    assert not np.isnan(out).any() and rel_err(out, ref) <= 1e-10
     plan.close()
 
 
