@@ -502,7 +502,7 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
             if (trace || rc)
                 fprintf(stderr, "[sparseframe-hip] factorize: %.2f GB of panels against a device budget of %.2f GB -> out of core: %d groups, "
                                 "top %.2f GB %s + 2 buffers of %.2f GB%s\n", entries * per_entry / 1e9, budget / 1e9, ooc_ngroups,
-                        te * per_entry / 1e9, ooc_mode == 1 ? "for the active top panels" : "resident", ge * per_entry / 1e9, rc == 2 ? " -- DOES NOT FIT" : "");
+                        te * per_entry / 1e9, ooc_mode == 0 ? "resident (top mode 0)" : (ooc_mode == 1 ? "for the active top panels (top mode 1)" : "for the active top panels (top mode 2)"), ge * per_entry / 1e9, rc == 2 ? " -- DOES NOT FIT" : "");
             return rc == 0 ? SF_OK : (rc == 2 ? SF_ERR_ALLOC : SF_ERR_ARG);
         };
         auto create = [&]() {

@@ -1166,12 +1166,15 @@ int ooc_partition(Long nsuper, const Long* Super, const Long* SuperMap, const Lo
     bool fits = total <= budget;
     if (!fits) {
         best_need = INT64_MAX;
-        for (int mode = 0; mode < 3 && !fits; ++mode) {
+        // modes in the order of their speed, each with at most 64 groups (hundreds of tiny groups cost more than the next mode does);
+        // then mode 2 with whatever number of groups it takes
+        for (int pass = 0; pass < 4 && !fits; ++pass) {
+            const int mode = std::min(pass, 2), max_groups = pass < 3 ? 64 : MAX_GROUPS;
             double S = (double)budget / 2.0;
             for (int it = 0; it < 96 && S >= 1.0; ++it, S *= 0.85) {
                 int ng = 0;
                 const int64_t nd = cut((int64_t)S, mode, group, &ng, nullptr, nullptr);
-                if (ng > MAX_GROUPS) break;
+                if (ng > max_groups) break;
                 if (nd < best_need) { best_need = nd; bestS = (int64_t)S; best_mode = mode; }
                 if (nd <= budget) { fits = true; break; }
             }

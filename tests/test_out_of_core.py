@@ -285,10 +285,13 @@ def test_out_of_core_lu_matches_the_oracle(oracle, tol):
 
 
 @pytest.mark.gpu
-def test_struct_entry_point_goes_out_of_core_under_a_budget(oracle, monkeypatch):
+@pytest.mark.parametrize("frac,mode", [(0.6, 0), (0.46, 1), (0.35, 2)])
+def test_struct_entry_point_goes_out_of_core_under_a_budget(oracle, monkeypatch, capfd, frac, mode):
     """SparseFrame_factorize with a device budget smaller than the factor: same Lsx, plan cached per pattern, the solve answers from
-    the host copy (nothing resident to solve with); without the budget the same handler list factorizes in core again"""
-    N = 24
+    the host copy (nothing resident to solve with).  The tighter the budget, the further down the ladder: top panels resident
+    (mode 0), resident while active (1), their places re-used at once (2)"""
+    monkeypatch.setenv("SF_TRACE", "1")
+    N = 32
     n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
     perm = nd_perm_py(N, N, N)
     S = sf.analyze(n, Cp, Ci, Cx, perm, 1 << 30)
@@ -297,7 +300,7 @@ def test_struct_entry_point_goes_out_of_core_under_a_budget(oracle, monkeypatch)
     total_mb = 8 * int(panel_entries(S).sum()) / 2**20
     # the budget counts the plan's tables and staging rings too (384 MiB + structure): leave the panels 60 % of their size
     overhead_mb = 384 + (12 * int(S.Lp[-1]) + 24 * len(S.Lsi)) / 2**20
-    monkeypatch.setenv("SF_DEVICE_BUDGET_MB", str(int(overhead_mb + 0.6 * total_mb)))
+    monkeypatch.setenv("SF_DEVICE_BUDGET_MB", str(int(overhead_mb + frac * total_mb) + 1))
     common = sf.CommonInfo(dev_slot_size=1 << 30)
     builds0 = common.plan_builds()
     solves0 = sf.lib.sf_handlers_resident_solves()
@@ -315,6 +318,7 @@ def test_struct_entry_point_goes_out_of_core_under_a_budget(oracle, monkeypatch)
         mi.cleanup()
     assert common.plan_builds() == builds0 + 1                      # one out-of-core plan for both calls
     assert sf.lib.sf_handlers_resident_solves() == solves0          # host sweep: no resident factor
+    assert f"(top mode {mode})" in capfd.readouterr().err
     common.close()
 
 

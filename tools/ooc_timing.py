@@ -36,10 +36,11 @@ run(plan, "in_core", {})
 ref_sample = out[:: max(1, S.xsize // 100003)].copy()
 plan.close()
 for f in fracs:
-    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * f))
-    plan = sf.CholPlan(S, ooc_group=g, ooc_ngroups=ng)
+    cut = sf.ooc_partition(S, int(total * f))
+    g, ng, ge, te, nd, fits = cut
+    plan = sf.CholPlan(S, ooc_group=g, ooc_ngroups=ng, ooc_top_mode=cut.top_mode)
     out[:] = np.nan
-    run(plan, "out_of_core", dict(budget_fraction=f, fits=bool(fits), groups=ng, top_GB=round(8 * te / 1e9, 2), buffer_GB=round(8 * ge / 1e9, 2),
+    run(plan, "out_of_core", dict(budget_fraction=f, fits=bool(fits), top_mode=cut.top_mode, groups=ng, top_GB=round(8 * te / 1e9, 2), buffer_GB=round(8 * ge / 1e9, 2),
                                   need_fraction=round(nd / total, 3)))
     got = out[:: max(1, S.xsize // 100003)]
     m = np.isfinite(ref_sample)
