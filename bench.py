@@ -675,13 +675,20 @@ def main():
         del Lsx
 
     if rank == 0 and ngpu == 1 and not args.no_secondary and not lu and args.workload == "lap3d" and args.grid in (0, 128):
-        out["secondary"] = {"config1": config1_case(sf, np), "config3": secondary_case(sf, np, "config3"),
-                            "config5": secondary_case(sf, np, "config5"),
-                            "config5_pivoting": secondary_case(sf, np, "config5_pivoting")}
+        def guarded(fn, *a, **kw):
+            # a secondary case that fails must not take the headline with it: its entry says what happened
+            try:
+                return fn(*a, **kw)
+            except Exception as e:      # noqa: BLE001 -- reported, not swallowed
+                return {"error": f"{type(e).__name__}: {e}"}
+
+        out["secondary"] = {"config1": guarded(config1_case, sf, np), "config3": guarded(secondary_case, sf, np, "config3"),
+                            "config5": guarded(secondary_case, sf, np, "config5"),
+                            "config5_pivoting": guarded(secondary_case, sf, np, "config5_pivoting")}
         plan.close()            # (the 30 GB of the headline plan make room; nothing below uses it)
         plan = None
-        out["secondary"]["out_of_core"] = out_of_core_case(sf, np, sym, in_core_log_det=out["config"].get("pcie_inclusive", {}).get("log_det_half"), inputs=inputs)
-        out["secondary"]["end_to_end"] = end_to_end_case(sf, np, N)
+        out["secondary"]["out_of_core"] = guarded(out_of_core_case, sf, np, sym, in_core_log_det=out["config"].get("pcie_inclusive", {}).get("log_det_half"), inputs=inputs)
+        out["secondary"]["end_to_end"] = guarded(end_to_end_case, sf, np, N)
 
     if args.cpu_grid < 0:
         args.cpu_grid = min(N, 128)
