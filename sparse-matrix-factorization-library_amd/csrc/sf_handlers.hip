@@ -485,6 +485,9 @@ int sf_handlers_factorize(struct common_info_struct* common, struct gpu_info_str
             int64_t budget = 0;
             if (const char* env = getenv("SF_DEVICE_BUDGET_MB")) budget = (int64_t)strtoll(env, nullptr, 10) << 20;
             if (budget <= 0) {
+                // (a small factor is not worth the question: the estimate of everything else a plan needs is generous, and a device that
+                //  is nearly full should still take a matrix of a few MB -- the allocation itself will tell)
+                if (entries * per_entry < ((int64_t)64 << 20)) { ooc_ngroups = 1; return SF_OK; }
                 size_t fr = 0, tot = 0;
                 if (hipSetDevice(H.gpuIndex_physical) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return SF_ERR_HIP;
                 budget = (int64_t)fr - ((int64_t)1 << 30);
