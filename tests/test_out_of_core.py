@@ -476,3 +476,29 @@ def test_the_handler_pool_lends_its_buffer_to_one_pattern_at_a_time(oracle, monk
     # again, rebuilt) evicts pattern 2 and allocates its own: the pool stays with pattern 3
     assert users == [14 ** 3, 14 ** 3, 18 ** 3, 18 ** 3]
     common.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("seed,n_,per_col,band", [(1, 1500, 3, None), (3, 3000, 6, 400), (4, 6000, 4, 60), (6, 2500, 5, 1200)])
+def test_out_of_core_on_random_patterns(oracle, monkeypatch, seed, n_, per_col, band, mode):
+    """irregular trees (the built-in ordering on random SPD patterns: wide roots over heavy fill, banded chains, lopsided subtrees)
+    through every top mode: whatever the cut looks like -- a chain that is all top, groups of very different sizes, top supernodes
+    without grouped descendants -- the factor is the oracle's"""
+    monkeypatch.setenv("SF_DL_SLOT_MB", "1")
+    n, Cp, Ci, Cx = gen.random_spd_lower(n_, per_col, seed=seed, bandwidth=band)
+    perm = sf.graph_nd_perm(n, Cp, Ci)
+    S = sf.analyze(n, Cp, Ci, Cx, perm, sf.REFERENCE_SLOT_1GPU)
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.3))
+    if ng < 2:
+        pytest.skip("this tree has nothing to stream")
+    plan = sf.CholPlan(S, ooc_group=g, ooc_ngroups=ng, ooc_top_mode=mode)
+    out = np.full(S.xsize, np.nan)
+    plan.factorize_to_host(S.Lx, out=out)
+    ref, info, _ = oracle.chol_factorize(S)
+    assert info == 0
+    mask = oracle.lower_mask(S)
+    assert not np.isnan(out[mask]).any()
+    assert rel_err(out, ref, mask) <= TOL_FACTOR
+    plan.close()
