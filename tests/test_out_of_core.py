@@ -502,3 +502,25 @@ def test_out_of_core_on_random_patterns(oracle, monkeypatch, seed, n_, per_col, 
     assert not np.isnan(out[mask]).any()
     assert rel_err(out, ref, mask) <= TOL_FACTOR
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_out_of_core_lu_general_matrix_with_partial_pivoting(oracle, mode):
+    """a general unsymmetric matrix (no diagonal dominance) with partial pivoting inside the blocks (tol 1), streamed: the pivot
+    sequence and the packed factor are the oracle's in every top mode"""
+    n, Cp, Ci, Cx = gen.unsymmetric_general(14, 14, 14, seed=22, diag_scale=1.0)
+    S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(14, 14, 14), 1 << 30, "lu", False)
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.3))
+    if ng < 2:
+        pytest.skip("this tree has nothing to stream")
+    ref, info, pivpos, pivinv, nper = oracle.lu_factorize_pivot(S, tol=0.3)
+    assert info == 0 and np.count_nonzero(pivpos != np.arange(n)) > 0
+    plan = sf.LUPlan(S, ooc_group=g, ooc_ngroups=ng, ooc_top_mode=mode)
+    plan.set_pivoting(0.3)
+    out = np.full(S.xsize, np.nan)
+    plan.factorize_to_host(S.Lx, S.Ux, out=out)
+    assert np.array_equal(plan.get_pivots(), pivpos)
+    assert not np.isnan(out).any() and rel_err(out, ref) <= 1e-10
+    plan.close()
