@@ -1014,7 +1014,7 @@ template <int MODE, bool DMA>
 __global__ void __launch_bounds__(GEMM_THREADS, GEMM_WAVES / 2)
 k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
        const uint32_t* __restrict__ kt_prefix, int ntasks, uint32_t u_lo, uint32_t u_hi,
-       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap, int* __restrict__ ticket, int whole_tiles) {
+       double* __restrict__ Lsx, const int32_t* __restrict__ RelMap, int* __restrict__ ticket, int whole_tiles, uint32_t min_units) {
     __shared__ int s_claim;
     __shared__ __attribute__((aligned(16))) double Ys[2][GEMM_BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Xs[2][GEMM_BK][LDS_LD];
@@ -1103,12 +1103,17 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 #endif
     } else {
         const uint32_t ra = (ph == 0) ? u_lo : tail_beg, rb = (ph == 0) ? head_end : u_hi;
-        const uint32_t U = (rb > ra) ? (rb - ra + G - 1) / G : 0;
-        if (rb <= ra || share * U >= rb - ra) {
+        // (a share of fewer than min_units K steps costs more in its epilogue -- a whole 128 x 128 tile of atomics, on elements that up
+        //  to G / tiles other workgroups add to at the same time -- than it saves: small launches run on fewer workgroups instead)
+        const uint32_t Ueq = (rb > ra) ? (rb - ra + G - 1) / G : 0, U = max(Ueq, min_units);
+        // (when the floor applies only some workgroups get a share: take them round-robin over the XCDs -- blockIdx -- instead of
+        //  XCD by XCD, or the first XCDs would do all the work)
+        const uint32_t sh = (U > Ueq) ? blockIdx.x : share;
+        if (rb <= ra || sh * U >= rb - ra) {
             if (ph == 0) { ph = 1; continue; }
             break;
         }
-        u = ra + share * U;
+        u = ra + sh * U;
         u_end = min(rb, u + U);
         ti = last_le_u32(kt_prefix, ntasks + 1, u);
     }
@@ -1319,6 +1324,9 @@ k_gemm(const GemmProb* __restrict__ probs, const GemmTask* __restrict__ tasks,
 // ---------------------------------------------------------------------------------------------------
 #ifndef SF_LU_STEP_WGS
 #define SF_LU_STEP_WGS 3
+#ifndef SF_GEMM_MIN_UNITS_DEFAULT
+#define SF_GEMM_MIN_UNITS_DEFAULT 16     // 16-deep K steps; swept in round 4: config 3 11.20 -> 10.99 ms, config 5 and 128^3 unchanged (tools/experiments/gemm_min_units.sh)
+#endif
 #ifndef SF_POTRF_PW
 #define SF_POTRF_PW 16        // columns per panel of the fused step's 64 x 64 POTRF (16 or 32; 32 measured slower, see k_step)
 #endif      // workgroups per CU the LU variant of k_step is compiled for (168 VGPRs; the throughput-bound launches of the lower levels want the third)
@@ -2163,19 +2171,20 @@ void launch_gemm(const GemmProb* probs, const GemmTask* tasks, const uint32_t* k
     const uint32_t grid = units < cap ? units : cap;
     // LDS-DMA staging is the default (68.9 vs 67.4 TFLOP/s at 16k x 16k x 4k, 552 vs 554 ms at 128^3); SF_GEMM_DMA=0 selects the
     // register-staged form (read per launch: the tests flip it)
+    static const uint32_t min_units = [] { const char* m = getenv("SF_GEMM_MIN_UNITS"); return (uint32_t)(m ? std::max(1, atoi(m)) : SF_GEMM_MIN_UNITS_DEFAULT); }();
     const char* e = sf_exp_env("SF_GEMM_DMA");
     const bool dma = e ? atoi(e) != 0 : true;
     if (dma) {
         if (mode == 1)
-            hipLaunchKernelGGL((k_gemm<1, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
+            hipLaunchKernelGGL((k_gemm<1, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles, min_units);
         else
-            hipLaunchKernelGGL((k_gemm<0, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
+            hipLaunchKernelGGL((k_gemm<0, true>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles, min_units);
         return;
     }
     if (mode == 1)
-        hipLaunchKernelGGL((k_gemm<1, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
+        hipLaunchKernelGGL((k_gemm<1, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles, min_units);
     else
-        hipLaunchKernelGGL((k_gemm<0, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles);
+        hipLaunchKernelGGL((k_gemm<0, false>), dim3(grid), dim3(GEMM_THREADS), 0, st, probs, tasks, kt_prefix, ntasks, u_lo, u_hi, Lsx, RelMap, ticket, whole_tiles, min_units);
 }
 
 }  // namespace sf
