@@ -82,7 +82,7 @@ int sf_chol_plan_destroy(sf_chol_plan* p) {
     (void)hipSetDevice(p->device);
     void* ptrs[] = {p->d_Lp, p->d_Li, p->d_Lx, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, p->d_Lsxp,
                     p->d_Lsx, p->d_info, p->d_potrf, p->d_trsm, p->d_steps, p->d_flags, p->d_tinv, p->d_probs, p->d_gtasks, p->d_stasks, p->d_ktprefix,
-                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_status, p->d_fill, p->d_solveT, p->d_solveT_list};
+                    p->d_Up, p->d_Ui, p->d_Ux, p->d_Xp, p->d_pack, p->d_piv, p->d_resid, p->d_loadmask, p->d_loadmapL, p->d_loadmapU, p->d_solve, p->d_solve_sync, p->d_x, p->d_relmap, p->d_scratch, p->d_status, p->d_fill, p->d_solveT, p->d_solveT_list};
     for (void* q : ptrs)
         if (q && !(q == (void*)p->d_Lsx && p->factor_borrowed)) (void)hipFree(q);      // (a borrowed factor buffer goes back to its lender)
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
@@ -1399,6 +1399,24 @@ static int plan_create(sf_chol_plan** out, int device, bool lu, sf_long n, sf_lo
                 p->bytes_device += ub;
             }
         }
+        if (!p->partial) {
+            // where every matrix entry goes (k_build_loadmap, once): the assembly of a whole plan is then one coalesced pass per
+            // factorization.  Plans with assembly masks (several ranks, out of core) keep the searching kernel.
+            const int64_t* xpm = lu ? p->d_Xp : p->d_Lsxp;
+            const size_t mbL = (size_t)std::max<int64_t>(p->nnz, 1) * sizeof(int64_t);
+            if (!dalloc((void**)&p->d_loadmapL, mbL)) { rc = SF_ERR_ALLOC; break; }
+            p->bytes_device += mbL;
+            if (!dry) sf::launch_build_loadmap(p->d_Lp, p->d_Li, (int32_t)n, p->d_Super, p->d_SuperMap, p->d_Lsip, p->d_Lsi, xpm, 0, lu ? 1 : 0, p->d_loadmapL, p->stream);
+            if (lu) {
+                const int64_t nzu = p->u_alias ? p->nnz : p->unz;
+                const size_t mbU = (size_t)std::max<int64_t>(nzu, 1) * sizeof(int64_t);
+                if (!dalloc((void**)&p->d_loadmapU, mbU)) { rc = SF_ERR_ALLOC; break; }
+                p->bytes_device += mbU;
+                if (!dry) sf::launch_build_loadmap(p->u_alias ? p->d_Lp : p->d_Up, p->u_alias ? p->d_Li : p->d_Ui, (int32_t)n, p->d_Super, p->d_SuperMap,
+                                                   p->d_Lsip, p->d_Lsi, xpm, p->xC, 0, p->d_loadmapU, p->stream);
+            }
+            if (!dry && (hipStreamSynchronize(p->stream) != hipSuccess || hipGetLastError() != hipSuccess)) { rc = SF_ERR_HIP; break; }
+        }
         // GEMM launches: 8 claim counters each (one per XCD) for the dynamic deal of their whole-tile rounds
         for (Launch& L : p->launches)
             if (L.kind == 2 || L.kind == 3 || L.kind == 4) { L.ticket = p->n_tickets; p->n_tickets += 8; }
@@ -1729,6 +1747,11 @@ static int run_launches(sf_chol_plan* p, size_t l0, size_t l1, bool first, bool 
     }
     // the matrix entries of the panels `mask` selects (nullptr: all) into the zeroed panels
     auto assemble = [&](const int8_t* mask, hipStream_t s_) {
+        if (!mask && p->d_loadmapL) {           // a whole plan: the entries' places are known (plan_create)
+            sf::launch_load_mapped(p->d_Lx, p->d_loadmapL, p->nnz, p->d_Lsx, s_);
+            if (p->lu) sf::launch_load_mapped(p->u_alias ? p->d_Lx : p->d_Ux, p->d_loadmapU, p->u_alias ? p->nnz : p->unz, p->d_Lsx, s_);
+            return;
+        }
         const int64_t* xp = (p->lu || p->partial) ? p->d_Xp : p->d_Lsxp;
         if (!p->lu) {
             sf::launch_load_panels(p->d_Lp, p->d_Li, p->d_Lx, (int32_t)p->n, p->d_Super, p->d_SuperMap, p->d_Lsip,

@@ -116,6 +116,9 @@ struct StepTask {   // fused 64-column step on rows [row0, row0+nrows) of panel 
 };
 
 // skip_diag != 0: entries with row == column are not stored (LU: the L panel)
+void launch_build_loadmap(const int64_t* Lp, const int32_t* Li, int32_t n, const int32_t* Super, const int32_t* SuperMap,
+                          const int64_t* Lsip, const int32_t* Lsi, const int64_t* Lsxp, int64_t base, int skip_diag, int64_t* map, hipStream_t st);
+void launch_load_mapped(const double* Lx, const int64_t* map, int64_t nnz, double* Lsx, hipStream_t st);
 void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
                         const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
                         const int64_t* Lsxp, double* Lsx, int skip_diag, const int8_t* load_mask, hipStream_t st);

@@ -69,6 +69,51 @@ k_load_panels(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, co
     }
 }
 
+// The same walk once per plan, keeping where every entry goes (offset into Lsx, -1: not loaded) -- so that the assembly of every
+// later factorization is one coalesced pass over the values and the map (k_load_mapped) instead of a binary search per entry in
+// dependent loads: config 3 (n = 10^6, 10^7 entries) 0.46 -> 0.07 ms per factorization.
+__global__ void __launch_bounds__(256)
+k_build_loadmap(const int64_t* __restrict__ Lp, const int32_t* __restrict__ Li, int32_t n,
+                const int32_t* __restrict__ Super, const int32_t* __restrict__ SuperMap,
+                const int64_t* __restrict__ Lsip, const int32_t* __restrict__ Lsi,
+                const int64_t* __restrict__ Lsxp, int64_t base, int skip_diag, int64_t* __restrict__ map) {
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t s = SuperMap[j];
+    const int32_t c0 = Super[s], c1 = Super[s + 1];
+    const int64_t r0 = Lsip[s];
+    const int32_t nsrow = (int32_t)(Lsip[s + 1] - r0);
+    const int32_t nscol = c1 - c0;
+    const int64_t col = base + Lsxp[s] + (int64_t)(j - c0) * nsrow;
+    const int32_t* below = Lsi + r0 + nscol;
+    for (int64_t p = Lp[j]; p < Lp[j + 1]; ++p) {
+        const int32_t i = Li[p];
+        if (skip_diag && i == j) { map[p] = -1; continue; }
+        const int32_t si = (i < c1) ? (i - c0) : nscol + lower_bound_i32(below, nsrow - nscol, i);
+        map[p] = col + si;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_load_mapped(const double* __restrict__ Lx, const int64_t* __restrict__ map, int64_t nnz, double* __restrict__ Lsx) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = map[p];
+        if (m >= 0) Lsx[m] = Lx[p];
+    }
+}
+
+void launch_build_loadmap(const int64_t* Lp, const int32_t* Li, int32_t n, const int32_t* Super, const int32_t* SuperMap,
+                          const int64_t* Lsip, const int32_t* Lsi, const int64_t* Lsxp, int64_t base, int skip_diag, int64_t* map, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_build_loadmap, dim3((n + 255) / 256), dim3(256), 0, st, Lp, Li, n, Super, SuperMap, Lsip, Lsi, Lsxp, base, skip_diag, map);
+}
+
+void launch_load_mapped(const double* Lx, const int64_t* map, int64_t nnz, double* Lsx, hipStream_t st) {
+    if (nnz <= 0) return;
+    const int64_t blocks = std::min<int64_t>((nnz + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_load_mapped, dim3((unsigned)blocks), dim3(256), 0, st, Lx, map, nnz, Lsx);
+}
+
 void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, int32_t n,
                         const int32_t* Super, const int32_t* SuperMap, const int64_t* Lsip, const int32_t* Lsi,
                         const int64_t* Lsxp, double* Lsx, int skip_diag, const int8_t* load_mask, hipStream_t st) {

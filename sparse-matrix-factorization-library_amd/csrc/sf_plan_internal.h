@@ -217,6 +217,7 @@ struct sf_chol_plan {
     int64_t packed_pending = -1;   // segment whose packed buffer has to be scattered back before it runs
     bool own_stream = true;
     int8_t* d_loadmask = nullptr;
+    int64_t *d_loadmapL = nullptr, *d_loadmapU = nullptr;      // whole plans: offset into d_Lsx of every entry of L (/ U), -1 = not loaded
     // device solve (Cholesky, whole matrix on one device): task lists per (level, 64-column step)
     sf::SolveTask* d_solve = nullptr;
     // backward sweep: row-major copies of the diagonal blocks of the top levels' steps (made at the start of every solve)
