@@ -491,7 +491,9 @@ k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx, const
     const int b = t.b;
     const int tid = threadIdx.x;
 
-    for (int e = tid; e < NB * NB; e += TRSM_ROWS) {
+    // (columns k >= b are never multiplied with: a 3-column panel of the bottom levels fills 3 x 64 entries, not 64 x 64 -- config 3 has
+    //  26,000 such panels; the entries Dt[k][j >= b] only reach sums that are not stored)
+    for (int e = tid; e < b * NB; e += (int)blockDim.x) {
         const int k = e / NB, j = e % NB;   // column k, row j of the block: coalesced along j
         Dt[k][j] = (j < b && k < j) ? Dg[j + (int64_t)k * t.ld] : 0.0;
     }
@@ -541,6 +543,8 @@ k_trsm_block(const TrsmTask* __restrict__ tasks, double* __restrict__ Lsx, const
     }
 }
 
+// (64-thread workgroups for launches whose tiles have at most 64 rows -- the bottom levels -- were measured: SLOWER, 0.47 against
+// 0.395 ms on config 3: the block's fill is what the other three waves are for)
 void launch_trsm(const TrsmTask* tasks, int ntasks, double* Lsx, const int32_t* pivinv, hipStream_t st) {
     if (ntasks <= 0) return;
     hipLaunchKernelGGL(k_trsm_block, dim3(ntasks), dim3(TRSM_ROWS), 0, st, tasks, Lsx, pivinv);
