@@ -524,3 +524,24 @@ def test_out_of_core_lu_general_matrix_with_partial_pivoting(oracle, mode):
     assert np.array_equal(plan.get_pivots(), pivpos)
     assert not np.isnan(out).any() and rel_err(out, ref) <= 1e-10
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 2])
+def test_out_of_core_with_the_three_launch_step_form(oracle, monkeypatch, mode):
+    """SF_FUSE_MAX=0: every 64-column step as stream-K GEMM + one-wave POTRF + TRSM launches instead of the fused step kernel -- the
+    other form of the chain, streamed"""
+    monkeypatch.setenv("SF_FUSE_MAX", "0")
+    N = 20
+    n, Cp, Ci, Cx = gen.laplacian_lower(N, N, N)
+    S = sf.analyze(n, Cp, Ci, Cx, nd_perm_py(N, N, N), 1 << 30)
+    total = int(panel_entries(S).sum())
+    g, ng, ge, te, nd, fits = sf.ooc_partition(S, int(total * 0.4))
+    assert ng >= 3
+    plan = sf.CholPlan(S, ooc_group=g, ooc_ngroups=ng, ooc_top_mode=mode)
+    out = np.full(S.xsize, np.nan)
+    plan.factorize_to_host(S.Lx, out=out)
+    ref, info, _ = oracle.chol_factorize(S)
+    mask = oracle.lower_mask(S)
+    assert rel_err(out, ref, mask) <= TOL_FACTOR
+    plan.close()
