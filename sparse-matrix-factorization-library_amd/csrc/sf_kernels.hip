@@ -129,6 +129,21 @@ void launch_load_panels(const int64_t* Lp, const int32_t* Li, const double* Lx, 
 // constant after unrolling, so the broadcast lands in SGPRs and feeds v_fma_f64 directly).
 // Rows/columns beyond b are padded with the identity.
 // ---------------------------------------------------------------------------------------------------
+// 1 / sqrt(v) and 1 / v to full fp64 accuracy from the hardware's 24-bit approximations (v_rsq_f64, v_rcp_f64: 5e-8 relative) and ONE
+// third-order step --  r (1 + e/2 + 3 e^2 / 8), e = 1 - v r^2;  c (1 + e + e^2), e = 1 - v c  -- instead of two Newton steps: one
+// dependent operation less on the sequential chains of the panel factorizations (5 instead of 6, 3 instead of 4) AND closer to the
+// correctly rounded value: 1.24 / 1.00 ulp worst case over 4 M arguments against 2.18 / 1.69 (tools/experiments/rsq_accuracy.hip).
+__device__ __forceinline__ double rsqrt_full(double v) {
+    const double r = __builtin_amdgcn_rsq(v);
+    const double e = __builtin_fma(-(v * r), r, 1.0);
+    return __builtin_fma(r, e * __builtin_fma(e, 0.375, 0.5), r);
+}
+__device__ __forceinline__ double rcp_full(double v) {
+    const double c = __builtin_amdgcn_rcp(v);
+    const double e = __builtin_fma(-v, c, 1.0);
+    return __builtin_fma(c, __builtin_fma(e, e, e), c);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -157,13 +172,12 @@ __device__ __forceinline__ void potrf_block_w(const PotrfTask& t, double* __rest
     for (int j = 0; j < W; ++j) {
         const double djj = readlane_f64(a[j], j);
         bad = bad || !(djj > 0.0);          // also catches NaN; padded rows have djj = 1
-        // 1/sqrt(djj) from v_rsq_f64 + two Newton steps (full fp64 accuracy for normal inputs), d = djj * rinv:
-        // the IEEE sqrt and divide sequences are ~10x longer and sit on the sequential critical path
-        double rinv = __builtin_amdgcn_rsq(djj);
-        rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
-        rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
-        const double d = djj * rinv;
-        const double lj = (lane == j) ? d : ((lane > j) ? a[j] * rinv : 0.0);
+        // 1/sqrt(djj) from v_rsq_f64 + one third-order step (rsqrt_full), the column scaled by it: the IEEE sqrt and divide sequences
+        // are ~10x longer and sit on the sequential critical path.  Every lane multiplies: lane j's own entry IS djj, so it gets
+        // djj / sqrt(djj) = the diagonal without a select; lanes above the diagonal carry values nobody reads (they only ever feed
+        // other entries above the diagonal, and the store below keeps to the lower triangle)
+        const double rinv = rsqrt_full(djj);
+        const double lj = a[j] * rinv;
         a[j] = lj;
 #pragma unroll
         for (int c = j + 1; c < W; ++c) a[c] -= lj * readlane_f64(lj, c);
@@ -237,9 +251,7 @@ __device__ __forceinline__ void getrf_panel_wave(double (&a)[W], int lane, int J
         const bool elim = active && lane != p;
         double l;
         if (RCP) {
-            double rp = __builtin_amdgcn_rcp(piv);
-            rp = rp * (2.0 - piv * rp);
-            rp = rp * (2.0 - piv * rp);
+            const double rp = rcp_full(piv);
             l = elim ? a[j] * rp : 0.0;
         } else {
             l = elim ? a[j] / piv : 0.0;
@@ -271,9 +283,7 @@ __device__ __forceinline__ bool getrf_panel_natural(double (&a)[W], int lane, in
         const bool below = lane > J;
         viol |= __ballot(below && !(tol * fabs(a[j]) <= fabs(piv)));            // a NaN entry counts as larger
         if (J < b && (!(fabs(piv) >= eps) || piv == 0.0)) viol |= 1ull;           // zero, NaN or tiny pivot (wave-uniform test)
-        double rp = __builtin_amdgcn_rcp(piv);
-        rp = rp * (2.0 - piv * rp);
-        rp = rp * (2.0 - piv * rp);
+        const double rp = rcp_full(piv);
         const double l = below ? a[j] * rp : 0.0;
         if (below) a[j] = l;
 #pragma unroll
@@ -1759,9 +1769,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 #pragma unroll
                 for (int c = 0; c < r; ++c) sacc -= Ub[r * sr + c * sc] * w[c];
                 const double trr = Ub[r * (ST_ULD + 1)];
-                double rp = __builtin_amdgcn_rcp(trr);
-                rp = rp * (2.0 - trr * rp);
-                rp = rp * (2.0 - trr * rp);
+                const double rp = rcp_full(trr);
                 w[r] = lset ? sacc : sacc * rp;
             }
             double* __restrict__ out = tinv + (int64_t)t.slot * 2048 + (lset ? 1024 : 0) + wave * 256 + j * 16;
@@ -1806,11 +1814,10 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                     if (PW > 16 && j == 16 && c0 + 16 >= b) break;          // narrow block: the rest of the panel is identity padding
                     const double djj = readlane_f64(a[j], c0 + j);
                     bad = bad || !(djj > 0.0);
-                    double rinv = __builtin_amdgcn_rsq(djj);
-                    rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
-                    rinv = rinv * (1.5 - 0.5 * djj * rinv * rinv);
-                    const double d = djj * rinv;
-                    const double lj = (lane == c0 + j) ? d : ((lane > c0 + j) ? a[j] * rinv : 0.0);
+                    // (rsqrt_full; no select: the diagonal lane's own entry is djj, lanes above the diagonal carry values nobody reads --
+                    //  see potrf_block_w)
+                    const double rinv = rsqrt_full(djj);
+                    const double lj = a[j] * rinv;
                     a[j] = lj;
 #pragma unroll
                     for (int c = j + 1; c < PW; ++c) a[c] -= lj * readlane_f64(lj, c0 + c);
@@ -1858,9 +1865,7 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
 #pragma unroll
                 for (int c = 0; c < r; ++c) sacc -= U[(o + c) * ST_ULD + o + r] * wv[c];
                 const double trr = U[(o + r) * ST_ULD + o + r];
-                double rp = __builtin_amdgcn_rcp(trr);
-                rp = rp * (2.0 - trr * rp);
-                rp = rp * (2.0 - trr * rp);
+                const double rp = rcp_full(trr);
                 wv[r] = sacc * rp;          // rows above the diagonal come out as exact zeros (zero right-hand side so far)
             }
             // Tinv_w(r, j) at tinv[slot][w][j][r]: the [k][i] image the consumers' MFMA A operand reads
