@@ -1809,18 +1809,23 @@ k_step(const StepTask* __restrict__ tasks, double* __restrict__ Lsx, int* __rest
                 double a[PW];
 #pragma unroll
                 for (int u = 0; u < PW; ++u) a[u] = U[(c0 + u) * ST_ULD + lane];
+                // dnext: what the NEXT column's diagonal entry will be, formed in its own lane (a[j+1] - lj^2 there: the same fused
+                // multiply-add as the general update below, whose multiplier for that lane is the lane's own lj) -- so the chain from one
+                // pivot to the next has ONE lane broadcast in it instead of two
+                double dnext = a[0];
 #pragma unroll
                 for (int j = 0; j < PW; ++j) {
                     if (PW > 16 && j == 16 && c0 + 16 >= b) break;          // narrow block: the rest of the panel is identity padding
-                    const double djj = readlane_f64(a[j], c0 + j);
+                    const double djj = readlane_f64(dnext, c0 + j);
                     bad = bad || !(djj > 0.0);
                     // (rsqrt_full; no select: the diagonal lane's own entry is djj, lanes above the diagonal carry values nobody reads --
                     //  see potrf_block_w)
                     const double rinv = rsqrt_full(djj);
                     const double lj = a[j] * rinv;
                     a[j] = lj;
+                    if (j + 1 < PW) dnext = __builtin_fma(-lj, lj, a[j + 1]);
 #pragma unroll
-                    for (int c = j + 1; c < PW; ++c) a[c] -= lj * readlane_f64(lj, c0 + c);
+                    for (int c = j + 1; c < PW; ++c) a[c] = __builtin_fma(-lj, readlane_f64(lj, c0 + c), a[c]);
                 }
 #pragma unroll
                 for (int u = 0; u < PW; ++u) {
