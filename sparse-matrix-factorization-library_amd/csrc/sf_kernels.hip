@@ -168,9 +168,10 @@ __device__ __forceinline__ void potrf_block_w(const PotrfTask& t, double* __rest
         a[c] = v;
     }
     bool bad = false;
+    double dnext = a[0];        // the next column's diagonal entry, formed in its own lane (see k_step's panel)
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        const double djj = readlane_f64(a[j], j);
+        const double djj = readlane_f64(dnext, j);
         bad = bad || !(djj > 0.0);          // also catches NaN; padded rows have djj = 1
         // 1/sqrt(djj) from v_rsq_f64 + one third-order step (rsqrt_full), the column scaled by it: the IEEE sqrt and divide sequences
         // are ~10x longer and sit on the sequential critical path.  Every lane multiplies: lane j's own entry IS djj, so it gets
@@ -179,8 +180,9 @@ __device__ __forceinline__ void potrf_block_w(const PotrfTask& t, double* __rest
         const double rinv = rsqrt_full(djj);
         const double lj = a[j] * rinv;
         a[j] = lj;
+        if (j + 1 < W) dnext = __builtin_fma(-lj, lj, a[j + 1]);
 #pragma unroll
-        for (int c = j + 1; c < W; ++c) a[c] -= lj * readlane_f64(lj, c);
+        for (int c = j + 1; c < W; ++c) a[c] = __builtin_fma(-lj, readlane_f64(lj, c), a[c]);
     }
     if (bad && lane == 0) atomicOr(info, 1);
 #pragma unroll
